@@ -1,0 +1,152 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark: iso3dfd 16th-order fp32, 1024^3 points per GPU (BASELINE.json configs[1]).
+
+A "step" is one pass of the hot path (yk_solution::run_solution over one time step: one HIP stencil
+launch per part, plus halo exchange when N>1) over the whole grid.  Metric: Gpoints/s =
+overall_domain_points * steps / elapsed (the reference's "throughput (num-points/sec)",
+src/kernel/lib/soln_apis.cpp:455-461), with all vars already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N>1 is launched by the driver as `python -m torch.distributed.run ... bench.py --gpus N`; the grid is
+decomposed in x (one 1024^3 block per GPU, weak scaling), halos travel as RCCL send/recv on a side
+stream overlapped with the interior kernel.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+BYTES_PER_POINT = 16.0       # read p(t) 4 + p(t-1) 4 + v 4, write p(t+1) 4
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(n=512, steps=10):
+    """Reference CPU kernel (oracle/_ref, unmodified intel/yask) timed on this host's cores on a
+    bounded sample of the same workload; falls back to the C restatement (kind 'port')."""
+    cores = os.cpu_count() or 1
+    flags = open("/proc/cpuinfo").read()
+    arch = "avx512" if "avx512f" in flags else "avx2"
+    exe = ROOT / "oracle" / "_ref" / "bin" / f"ref_driver.iso3dfd.{arch}.exe"
+    sample = f"iso3dfd r=8 fp32 {n}^3 x {steps} steps (same stencil, 1/8 of the grid)"
+    if exe.exists():
+        try:
+            out = subprocess.run([str(exe), "-g", str(n), "-steps", str(steps), "-threads", str(cores), "-trials", "2",
+                                  "-init", "v:150:50"], capture_output=True, text=True, timeout=600)
+            for line in out.stdout.splitlines():
+                if line.startswith("{"):
+                    j = json.loads(line)
+                    return {"value": round(j["gpoints_per_s"], 4), "unit": "Gpoints/s", "cores": int(j["threads"]),
+                            "kind": "reference", "sample": sample + f", yask target {j['target']}, best of 2 trials"}
+        except Exception as e:  # noqa: BLE001
+            print("cpu_baseline: reference run failed:", e, file=sys.stderr)
+    from oracle import oracle as O
+    import numpy as np
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    n2, st2 = 256, 4
+    t0 = time.time()
+    O.run_iso3dfd((n2, n2, n2), st2, dtype=np.float32)
+    dt = time.time() - t0
+    return {"value": round(n2 ** 3 * st2 / dt * 1e-9, 4), "unit": "Gpoints/s", "cores": cores, "kind": "port",
+            "sample": f"C restatement (oracle/stencil_oracle.c, OpenMP) {n2}^3 x {st2} steps incl. init"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=1024, help="points per GPU in each dim")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"])
+    ap.add_argument("--opts", default="", help="extra yask options, e.g. '-hip_variant NAME'")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from yask_amd import yk_factory, dist as ydist
+
+    rank, local_rank, world = ydist.init_process_group()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    fac = yk_factory("iso3dfd")
+    env, transport = ydist.new_env(fac, args.transport)
+    soln = fac.new_solution(env)
+    n = args.size
+    # x-slab decomposition: x-faces are whole contiguous planes and each GPU has only 2 neighbours
+    soln.set_num_ranks_vec([world, 1, 1])
+    soln.set_rank_domain_size_vec([n, n, n])
+    if args.opts:
+        rem = soln.apply_command_line_options(args.opts)
+        assert rem == "", rem
+    soln.prepare_solution()
+    soln.get_var("p").set_elements_hash(0.0, 1.0, hash_id=0)
+    soln.get_var("v").set_elements_hash(150.0, 50.0, hash_id=1)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    t = 0
+    if args.warmup > 0:
+        soln.run_solution(t, t + args.warmup - 1)
+        t += args.warmup
+    soln.get_stats()
+    barrier()
+    t0 = time.perf_counter()
+    soln.run_solution(t, t + args.steps - 1)      # returns after the streams have drained
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t += args.steps
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    pts_per_gpu = float(n) ** 3
+    total_pts = pts_per_gpu * world
+    value = total_pts * args.steps / elapsed * 1e-9
+
+    # dominant kernel: average launch duration by HIP events on the compute stream, same launches
+    kern_ms = soln.time_part(part=0, variant=-1, t=t, reps=max(10, min(args.steps, 50)))
+    achieved = BYTES_PER_POINT * pts_per_gpu / (kern_ms * 1e-3) * 1e-9
+    traffic = None
+    tf = ROOT / "profiles" / "hbm_traffic.json"
+    if tf.exists():
+        try:
+            traffic = json.load(open(tf)).get("iso3dfd_1024_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "Gpoints/s (grid updates/s), iso3dfd 16th-order fp32",
+            "value": round(value, 3), "unit": "Gpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (logical-index hash init, random-like)",
+            "config": {"workload": f"iso3dfd r=8 fp32, {n}^3 points per GPU, global {n * world}x{n}x{n}",
+                       "decomposition": f"x-slabs {world}x1x1", "halo_transport": transport,
+                       "kernel": soln.get_kernel_variant(0), "overlap_comms": True},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": BYTES_PER_POINT * pts_per_gpu},
+            "gpoints_per_s_per_gpu": round(value / world, 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

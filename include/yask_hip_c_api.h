@@ -1,0 +1,219 @@
+/* yask_hip_c_api.h -- C ABI of the MI355X (cdna4_hip) YASK kernel library.
+ *
+ * One shared library per stencil solution, named like the reference's
+ * (lib/libyask_kernel.<stencil>.<arch>.so, src/common/common.mk:211-216):
+ *     libyask_kernel.<stencil>.cdna4_hip.so
+ * Every library exports exactly the symbols declared here.  The reference has no C ABI: its
+ * boundary is the C++ virtual API of include/yask_kernel_api.hpp, include/aux/yk_solution_api.hpp
+ * and include/aux/yk_var_api.hpp, normally reached from other languages through SWIG
+ * (src/kernel/swig/yask_kernel_api.i).  Each entry point below names the C++ method it stands for
+ * ("replaces: file:line"); argument meaning, index conventions (global / overall-domain indices,
+ * inclusive slice bounds, row-major buffers in the var's own dim order) and error behaviour follow
+ * that method.  Bindings: INTEGRATION.md shows the yk_* C++ adapter (yask_amd/cxxapi) and the
+ * ctypes binding (yask_amd/_capi.py) built on these calls.
+ *
+ * Conventions
+ *   - plain C types only; handles are opaque pointers owned by the library;
+ *   - every function returning `int` returns 0 on success and non-zero on failure; the failure
+ *     text (always starting with "YASK error: ", like yask::yask_exception::get_message(),
+ *     include/yask_common_api.hpp:125-179) is then available from yk_last_error();
+ *   - functions returning a value report failure through yk_last_error_code() != 0;
+ *   - like the reference API the library is not thread-safe: one calling thread per process,
+ *     and collective calls (prepare/run/exchange/tune) must be made on all ranks;
+ *   - there is no CPU fallback: creating an env without a visible AMD GPU fails.
+ */
+#ifndef YASK_HIP_C_API_H
+#define YASK_HIP_C_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int64_t yk_idx_t;               /* yask::idx_t, include/yask_common_api.hpp:86 */
+typedef struct yk_env_s* yk_env_h;      /* yask::yk_env      */
+typedef struct yk_solution_s* yk_soln_h;/* yask::yk_solution */
+typedef struct yk_var_s* yk_var_h;      /* yask::yk_var (borrowed from its solution; valid until yk_free_solution) */
+
+/* ---- errors ---- */
+const char* yk_last_error(void);        /* text of the last failure on this thread ("" if none) */
+int yk_last_error_code(void);           /* 0 if the last call succeeded */
+void yk_clear_error(void);
+
+/* ---- factory: replaces yk_factory, include/yask_kernel_api.hpp:82-161 ---- */
+const char* yk_get_version_string(void);                 /* yk_factory::get_version_string, :91 */
+yk_env_h yk_new_env(void);                               /* yk_factory::new_env(), :123 */
+void yk_free_env(yk_env_h env);
+yk_soln_h yk_new_solution(yk_env_h env);                 /* yk_factory::new_solution(env), :145 */
+yk_soln_h yk_new_solution_from(yk_env_h env, yk_soln_h source);   /* new_solution(env, source), :156: copies settings */
+void yk_free_solution(yk_soln_h soln);
+
+/* ---- env: replaces yk_env, include/yask_kernel_api.hpp:167-295 ---- */
+int yk_env_get_num_ranks(yk_env_h env);                  /* :238 */
+int yk_env_get_rank_index(yk_env_h env);                 /* :245 */
+int yk_env_global_barrier(yk_env_h env);                 /* :253 */
+yk_idx_t yk_env_sum_over_ranks(yk_env_h env, yk_idx_t v);/* :262 */
+void yk_env_set_trace_enabled(yk_env_h env, int enable); /* yk_env::set_trace_enabled, :221 */
+/* Multi-GPU: one process per GPU. The reference takes an MPI communicator (new_env(MPI_Comm), :136);
+ * here the host states rank/size and installs a halo transport. */
+int yk_env_set_ranks(yk_env_h env, int rank, int num_ranks);
+typedef struct {
+    int peer;            /* neighbour rank */
+    void* send_buf;      /* contiguous device buffers */
+    void* recv_buf;
+    size_t send_bytes, recv_bytes;
+    int tag;
+} yk_halo_msg;
+/* start: enqueue all transfers ordered after prior work on `stream` (a hipStream_t);
+ * wait : make later work on `stream` see the received bytes. Return 0 on success. */
+typedef int (*yk_exchange_fn)(void* user, int nmsgs, const yk_halo_msg* msgs, void* stream);
+typedef int (*yk_allreduce_fn)(void* user, int op /*0 sum, 1 min, 2 max*/, long long* val);
+int yk_env_set_transport(yk_env_h env, yk_exchange_fn start, yk_exchange_fn wait, yk_allreduce_fn allreduce, void* user);
+/* Built-in transport: RCCL ncclSend/ncclRecv over xGMI. `unique_id` is the 128-byte ncclUniqueId made
+ * by yk_rccl_get_unique_id() on rank 0 and distributed by the host (MPI_Bcast, torch.distributed ...). */
+int yk_rccl_get_unique_id(void* unique_id_128);
+int yk_env_init_rccl(yk_env_h env, const void* unique_id_128, int rank, int num_ranks);
+
+/* ---- solution: replaces yk_solution, include/aux/yk_solution_api.hpp:82-1292 ---- */
+const char* yk_solution_get_name(yk_soln_h s);                               /* :90 */
+const char* yk_solution_get_description(yk_soln_h s);                        /* :98 */
+const char* yk_solution_get_target(yk_soln_h s);                             /* :107 -> "cdna4_hip" */
+int yk_solution_is_offloaded(yk_soln_h s);                                   /* :114 -> 1 */
+int yk_solution_get_element_bytes(yk_soln_h s);                              /* :121 */
+const char* yk_solution_get_step_dim_name(yk_soln_h s);                      /* :130 */
+int yk_solution_get_num_domain_dims(yk_soln_h s);                            /* :140 */
+const char* yk_solution_get_domain_dim_name(yk_soln_h s, int i);             /* get_domain_dim_names, :149 */
+int yk_solution_get_num_misc_dims(yk_soln_h s);
+const char* yk_solution_get_misc_dim_name(yk_soln_h s, int i);               /* get_misc_dim_names, :161 */
+int yk_solution_set_rank_domain_size(yk_soln_h s, const char* dim, yk_idx_t size);     /* :187 */
+yk_idx_t yk_solution_get_rank_domain_size(yk_soln_h s, const char* dim);               /* :221 */
+int yk_solution_set_overall_domain_size(yk_soln_h s, const char* dim, yk_idx_t size);  /* :244 */
+yk_idx_t yk_solution_get_overall_domain_size(yk_soln_h s, const char* dim);            /* :281 */
+int yk_solution_set_block_size(yk_soln_h s, const char* dim, yk_idx_t size);           /* :316 */
+yk_idx_t yk_solution_get_block_size(yk_soln_h s, const char* dim);                     /* :356 */
+int yk_solution_set_num_ranks(yk_soln_h s, const char* dim, yk_idx_t n);               /* :404 */
+yk_idx_t yk_solution_get_num_ranks(yk_soln_h s, const char* dim);                      /* :436 */
+int yk_solution_set_rank_index(yk_soln_h s, const char* dim, yk_idx_t n);              /* :475 */
+yk_idx_t yk_solution_get_rank_index(yk_soln_h s, const char* dim);                     /* :505 */
+/* apply_command_line_options, :557: returns unrecognised tokens in `rem` (NUL terminated, truncated to rem_cap) */
+int yk_solution_apply_command_line_options(yk_soln_h s, const char* args, char* rem, size_t rem_cap);
+const char* yk_solution_get_command_line_help(yk_soln_h s);                  /* :586 */
+const char* yk_solution_get_command_line_values(yk_soln_h s);                /* :596 */
+int yk_solution_get_num_vars(yk_soln_h s);                                   /* :607 */
+yk_var_h yk_solution_get_var(yk_soln_h s, const char* name);                 /* :616 */
+yk_var_h yk_solution_get_var_by_index(yk_soln_h s, int i);                   /* get_vars, :624 */
+int yk_solution_prepare(yk_soln_h s);                                        /* prepare_solution, :638 */
+yk_idx_t yk_solution_get_first_rank_domain_index(yk_soln_h s, const char* dim);        /* :654 */
+yk_idx_t yk_solution_get_last_rank_domain_index(yk_soln_h s, const char* dim);         /* :681 */
+int yk_solution_run(yk_soln_h s, yk_idx_t first_step_index, yk_idx_t last_step_index); /* run_solution, :729/:759 */
+int yk_solution_end(yk_soln_h s);                                            /* end_solution, :775 */
+int yk_solution_exchange_halos(yk_soln_h s);                                 /* exchange_halos, :791 */
+int yk_solution_copy_vars_to_device(yk_soln_h s);                            /* :799 (no-op: vars live on the device) */
+int yk_solution_copy_vars_from_device(yk_soln_h s);                          /* :808 (no-op) */
+typedef struct {                                                             /* yk_stats, :1300-1348 */
+    yk_idx_t num_elements;       /* get_num_elements      */
+    yk_idx_t num_steps_done;     /* get_num_steps_done    */
+    yk_idx_t num_writes_done;    /* get_num_writes_done   */
+    yk_idx_t est_fp_ops_done;    /* get_est_fp_ops_done   */
+    double elapsed_secs;         /* get_elapsed_secs      */
+    /* extensions */
+    yk_idx_t num_reads_done;
+    double halo_secs;
+    double points_per_sec;       /* "throughput (num-points/sec)", soln_apis.cpp:455-461 */
+} yk_stats_t;
+int yk_solution_get_stats(yk_soln_h s, yk_stats_t* out);                     /* get_stats, :819 (clears the counters) */
+int yk_solution_reset_auto_tuner(yk_soln_h s, int enable, int verbose);      /* :838 */
+int yk_solution_is_auto_tuner_enabled(yk_soln_h s);                          /* :855 */
+int yk_solution_run_auto_tuner_now(yk_soln_h s, int verbose);                /* :880 */
+yk_var_h yk_solution_new_var(yk_soln_h s, const char* name, int ndims, const char* const* dims);      /* :994 */
+yk_var_h yk_solution_new_fixed_size_var(yk_soln_h s, const char* name, int ndims, const char* const* dims,
+                                        const yk_idx_t* sizes);                                      /* :1069 */
+/* extensions used by harness/validation (the reference reaches into StencilContext for these,
+ * src/kernel/yask_main.cpp:572-616) */
+yk_idx_t yk_solution_compare_data(yk_soln_h s, yk_soln_h ref, double epsilon);   /* compare_data, context.cpp:1529 */
+int yk_solution_set_streams(yk_soln_h s, void* compute_stream, void* comm_stream);
+const char* yk_solution_get_kernel_variant(yk_soln_h s, int part);
+int yk_solution_get_num_kernel_variants(yk_soln_h s, int part);
+const char* yk_solution_get_kernel_variant_name(yk_soln_h s, int part, int i);
+/* Launch part `part` of step t once with variant i (or the selected one if i < 0) on the compute
+ * stream, bracketed by HIP events; returns the kernel duration in ms in *ms. Used by bench.py. */
+int yk_solution_time_part(yk_soln_h s, int part, int variant, yk_idx_t xchunk, yk_idx_t t, int reps, float* ms);
+
+/* ---- var: replaces yk_var, include/aux/yk_var_api.hpp:185-1490 ---- */
+const char* yk_var_get_name(yk_var_h v);                                     /* :195 */
+int yk_var_get_num_dims(yk_var_h v);                                         /* :204 */
+const char* yk_var_get_dim_name(yk_var_h v, int i);                          /* get_dim_names, :212 */
+int yk_var_is_dim_used(yk_var_h v, const char* dim);                         /* :230 */
+int yk_var_is_fixed_size(yk_var_h v);                                        /* :237 */
+yk_idx_t yk_var_get_first_local_index(yk_var_h v, const char* dim);          /* :253 */
+yk_idx_t yk_var_get_last_local_index(yk_var_h v, const char* dim);           /* :275 */
+yk_idx_t yk_var_get_alloc_size(yk_var_h v, const char* dim);                 /* :294 */
+yk_idx_t yk_var_get_first_valid_step_index(yk_var_h v);                      /* :322 */
+yk_idx_t yk_var_get_last_valid_step_index(yk_var_h v);                       /* :335 */
+yk_idx_t yk_var_get_rank_domain_size(yk_var_h v, const char* dim);           /* :350 */
+yk_idx_t yk_var_get_first_rank_domain_index(yk_var_h v, const char* dim);    /* :371 */
+yk_idx_t yk_var_get_last_rank_domain_index(yk_var_h v, const char* dim);     /* :393 */
+yk_idx_t yk_var_get_left_halo_size(yk_var_h v, const char* dim);             /* :410 */
+yk_idx_t yk_var_get_right_halo_size(yk_var_h v, const char* dim);            /* :421 */
+yk_idx_t yk_var_get_first_rank_halo_index(yk_var_h v, const char* dim);      /* :434 */
+yk_idx_t yk_var_get_last_rank_halo_index(yk_var_h v, const char* dim);       /* :455 */
+yk_idx_t yk_var_get_left_pad_size(yk_var_h v, const char* dim);              /* :474 */
+yk_idx_t yk_var_get_right_pad_size(yk_var_h v, const char* dim);             /* :486 */
+yk_idx_t yk_var_get_left_extra_pad_size(yk_var_h v, const char* dim);        /* :500 */
+yk_idx_t yk_var_get_right_extra_pad_size(yk_var_h v, const char* dim);       /* :514 */
+yk_idx_t yk_var_get_first_misc_index(yk_var_h v, const char* dim);           /* :526 */
+yk_idx_t yk_var_get_last_misc_index(yk_var_h v, const char* dim);            /* :538 */
+int yk_var_set_left_min_pad_size(yk_var_h v, const char* dim, yk_idx_t n);   /* :1163 */
+int yk_var_set_right_min_pad_size(yk_var_h v, const char* dim, yk_idx_t n);  /* :1187 */
+int yk_var_set_min_pad_size(yk_var_h v, const char* dim, yk_idx_t n);        /* :1197 */
+int yk_var_set_left_halo_size(yk_var_h v, const char* dim, yk_idx_t n);      /* :1213 */
+int yk_var_set_right_halo_size(yk_var_h v, const char* dim, yk_idx_t n);     /* :1229 */
+int yk_var_set_halo_size(yk_var_h v, const char* dim, yk_idx_t n);           /* :1240 */
+int yk_var_set_first_misc_index(yk_var_h v, const char* dim, yk_idx_t idx);  /* :1286 */
+int yk_var_set_alloc_size(yk_var_h v, const char* dim, yk_idx_t n);          /* :1264 (step / misc dims) */
+int yk_var_are_indices_local(yk_var_h v, const yk_idx_t* indices);           /* :552 */
+double yk_var_get_element(yk_var_h v, const yk_idx_t* indices);              /* :577 */
+yk_idx_t yk_var_set_element(yk_var_h v, double val, const yk_idx_t* indices, int strict_indices);      /* :604 */
+yk_idx_t yk_var_add_to_element(yk_var_h v, double val, const yk_idx_t* indices, int strict_indices);   /* :772 */
+yk_idx_t yk_var_get_elements_in_slice_f32(yk_var_h v, float* buf, size_t buf_elems,
+                                          const yk_idx_t* first, const yk_idx_t* last);                /* :699 */
+yk_idx_t yk_var_get_elements_in_slice_f64(yk_var_h v, double* buf, size_t buf_elems,
+                                          const yk_idx_t* first, const yk_idx_t* last);                /* :727 */
+yk_idx_t yk_var_set_elements_in_slice_f32(yk_var_h v, const float* buf, size_t buf_elems,
+                                          const yk_idx_t* first, const yk_idx_t* last);                /* :876 */
+yk_idx_t yk_var_set_elements_in_slice_f64(yk_var_h v, const double* buf, size_t buf_elems,
+                                          const yk_idx_t* first, const yk_idx_t* last);                /* :905 */
+yk_idx_t yk_var_set_elements_in_slice_same(yk_var_h v, double val, const yk_idx_t* first,
+                                           const yk_idx_t* last, int strict_indices);                  /* :820 */
+int yk_var_set_all_elements_same(yk_var_h v, double val);                                             /* :800 */
+typedef struct {                                                             /* yk_var::yk_reduction_result, :960-1030 */
+    int reduction_mask;
+    yk_idx_t num_elements_reduced;
+    double sum, sum_squares, product, max, min;
+} yk_reduction_t;
+/* mask bits as yk_var::yk_reduction_mask: 1 sum, 2 sum of squares, 4 product, 8 max, 16 min */
+int yk_var_reduce_elements_in_slice(yk_var_h v, int mask, const yk_idx_t* first, const yk_idx_t* last,
+                                    int strict_indices, yk_reduction_t* out);                         /* :1040 */
+int yk_var_get_halo_exchange_l1_norm(yk_var_h v);                            /* :1101 */
+int yk_var_set_halo_exchange_l1_norm(yk_var_h v, int norm);                  /* :1118 */
+int yk_var_is_dynamic_step_alloc(yk_var_h v);                                /* :1131 */
+int yk_var_is_storage_allocated(yk_var_h v);                                 /* :1316 */
+yk_idx_t yk_var_get_num_storage_bytes(yk_var_h v);                           /* :1325 */
+yk_idx_t yk_var_get_num_storage_elements(yk_var_h v);                        /* :1333 */
+int yk_var_alloc_storage(yk_var_h v);                                        /* :1342 */
+int yk_var_release_storage(yk_var_h v);                                      /* :1352 */
+int yk_var_is_storage_layout_identical(yk_var_h v, yk_var_h other);          /* :1363 */
+int yk_var_fuse_vars(yk_var_h v, yk_var_h source);                           /* :1395 */
+void* yk_var_get_raw_storage_buffer(yk_var_h v);                             /* :1437: host mirror, refreshed by this call */
+int yk_var_sync_raw_storage_to_device(yk_var_h v);                           /* push edits of the mirror back */
+void* yk_var_get_device_storage(yk_var_h v);                                 /* device pointer of the allocation */
+/* extension: fill domain+halo of every step slot with offset + scale*H(hash_id, slot, x, y, z), the
+ * layout-independent logical-index hash shared with the oracle (oracle/stencil_oracle.c). */
+int yk_var_set_elements_hash(yk_var_h v, double offset, double scale, int hash_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YASK_HIP_C_API_H */

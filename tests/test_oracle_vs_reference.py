@@ -1,0 +1,74 @@
+"""Pins the CPU oracle (oracle/stencil_oracle.c) against outputs of the unmodified reference.
+
+The reference stores no golden vectors; tests/golden/*.npz were produced by
+running the reference's own optimized CPU kernel through its public API on this container
+(tests/golden/make_golden.py).  Tolerances: the reference's vector path and its scalar path differ
+by rounding order, and it accepts 1e-3 (src/kernel/lib/realv.hpp:974-994); we require far tighter:
+fp32 rel-Linf <= 2e-6 per case, fp64 <= 1e-13.
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+G = Path(__file__).resolve().parent / "golden"
+INDEX = json.load(open(G / "index.json"))
+
+
+def _load(name):
+    z = np.load(G / f"{name}.npz")
+    return {tuple([k.split("@")[0], int(k.split("@")[1])]): z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("name", [n for n in INDEX if INDEX[n]["stencil"] == "iso3dfd"])
+def test_iso3dfd_matches_reference(name):
+    meta, ref = INDEX[name], _load(name)
+    mine = O.run_iso3dfd(tuple(meta["size"]), meta["steps"])
+    for k, r in ref.items():
+        assert mine[k].shape == r.shape
+        assert O.rel_linf(mine[k], r) <= 2e-6, (k, O.rel_linf(mine[k], r))
+        assert O.within_tolerance(mine[k], r).all()
+    # inputs are reproduced bit-exactly (hash init is integer arithmetic)
+    assert np.array_equal(mine[("v", 0)], ref[("v", 0)])
+
+
+@pytest.mark.parametrize("name", [n for n in INDEX if INDEX[n]["stencil"] == "3axis"])
+def test_axis3_matches_reference(name):
+    meta, ref = INDEX[name], _load(name)
+    mine = O.run_axis3(tuple(meta["size"]), meta["steps"], radius=4, dtype=np.float64)
+    for k, r in ref.items():
+        assert O.rel_linf(mine[k], r) <= 1e-13, (k, O.rel_linf(mine[k], r))
+
+
+@pytest.mark.parametrize("name", [n for n in INDEX if INDEX[n]["stencil"] == "ssg"])
+def test_ssg_matches_reference(name):
+    meta, ref = INDEX[name], _load(name)
+    mine = O.run_ssg(tuple(meta["size"]), meta["steps"])
+    for k, r in ref.items():
+        scale = max(1e-30, float(np.abs(r).max()))
+        err = float(np.abs(mine[k].astype(np.float64) - r).max()) / scale
+        assert err <= 5e-6, (k, err)
+
+
+def test_fd_coefficients_closed_form():
+    # closed form c_k = 2(-1)^(k+1) (r!)^2 / (k^2 (r-k)! (r+k)!), c_0 = -2 sum c_k  
+    from math import factorial as f
+    r = 8
+    w = O.center_fd_coefficients(2, r)
+    for k in range(1, r + 1):
+        ck = 2 * (-1) ** (k + 1) * f(r) ** 2 / (k * k * f(r - k) * f(r + k))
+        assert abs(w[r + k] - ck) < 1e-14 and abs(w[r - k] - ck) < 1e-14
+    assert abs(w[r] + 2 * sum(w[r + 1:])) < 1e-13
+    c = O.iso3dfd_coeffs(8)
+    assert abs(c[0] - (-3.665812925170066e-03)) < 1e-17
+    assert abs(c[8] - (-9.712509712509679e-10)) < 1e-22
+
+
+def test_hash_is_layout_independent():
+    a = O.fill((4, 5, 6), 2, vid=3, slot=1, offset=0.5, scale=2.0, dtype=np.float64, origin=(10, 20, 30))
+    assert a.shape == (8, 9, 10)
+    assert a[2 + 1, 2 + 2, 2 + 3] == 0.5 + 2.0 * O.hash_unit(3, 1, 11, 22, 33)
+    assert -1.0 <= O.hash_unit(0, 0, 0, 0, 0) < 1.0

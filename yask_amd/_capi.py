@@ -1,0 +1,199 @@
+"""ctypes binding of the C ABI in include/yask_hip_c_api.h.
+
+Loads `yask_amd/lib/libyask_kernel.<stencil>.cdna4_hip.so` (built in-tree by yask_amd/csrc/Makefile)
+and declares the prototype of every exported entry point.  There is deliberately no fallback: if the
+library is missing the import of a solution fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_DIR = _PKG / "lib"
+HEADER = _PKG.parent / "include" / "yask_hip_c_api.h"
+
+idx_t = C.c_int64
+
+
+class YkStats(C.Structure):
+    _fields_ = [("num_elements", idx_t), ("num_steps_done", idx_t), ("num_writes_done", idx_t),
+                ("est_fp_ops_done", idx_t), ("elapsed_secs", C.c_double), ("num_reads_done", idx_t),
+                ("halo_secs", C.c_double), ("points_per_sec", C.c_double)]
+
+
+class YkReduction(C.Structure):
+    _fields_ = [("reduction_mask", C.c_int), ("num_elements_reduced", idx_t), ("sum", C.c_double),
+                ("sum_squares", C.c_double), ("product", C.c_double), ("max", C.c_double), ("min", C.c_double)]
+
+
+class YkHaloMsg(C.Structure):
+    _fields_ = [("peer", C.c_int), ("send_buf", C.c_void_p), ("recv_buf", C.c_void_p),
+                ("send_bytes", C.c_size_t), ("recv_bytes", C.c_size_t), ("tag", C.c_int)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(YkHaloMsg), C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_longlong))
+
+_H = C.c_void_p          # opaque handles
+_S = C.c_char_p
+_IP = C.POINTER(idx_t)
+
+# name -> (restype, argtypes); kept in the same order as the header.
+PROTOTYPES = {
+    "yk_last_error": (_S, []),
+    "yk_last_error_code": (C.c_int, []),
+    "yk_clear_error": (None, []),
+    "yk_get_version_string": (_S, []),
+    "yk_new_env": (_H, []),
+    "yk_free_env": (None, [_H]),
+    "yk_new_solution": (_H, [_H]),
+    "yk_new_solution_from": (_H, [_H, _H]),
+    "yk_free_solution": (None, [_H]),
+    "yk_env_get_num_ranks": (C.c_int, [_H]),
+    "yk_env_get_rank_index": (C.c_int, [_H]),
+    "yk_env_global_barrier": (C.c_int, [_H]),
+    "yk_env_sum_over_ranks": (idx_t, [_H, idx_t]),
+    "yk_env_set_trace_enabled": (None, [_H, C.c_int]),
+    "yk_env_set_ranks": (C.c_int, [_H, C.c_int, C.c_int]),
+    "yk_env_set_transport": (C.c_int, [_H, EXCHANGE_FN, EXCHANGE_FN, ALLREDUCE_FN, C.c_void_p]),
+    "yk_rccl_get_unique_id": (C.c_int, [C.c_void_p]),
+    "yk_env_init_rccl": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
+    "yk_solution_get_name": (_S, [_H]),
+    "yk_solution_get_description": (_S, [_H]),
+    "yk_solution_get_target": (_S, [_H]),
+    "yk_solution_is_offloaded": (C.c_int, [_H]),
+    "yk_solution_get_element_bytes": (C.c_int, [_H]),
+    "yk_solution_get_step_dim_name": (_S, [_H]),
+    "yk_solution_get_num_domain_dims": (C.c_int, [_H]),
+    "yk_solution_get_domain_dim_name": (_S, [_H, C.c_int]),
+    "yk_solution_get_num_misc_dims": (C.c_int, [_H]),
+    "yk_solution_get_misc_dim_name": (_S, [_H, C.c_int]),
+    "yk_solution_set_rank_domain_size": (C.c_int, [_H, _S, idx_t]),
+    "yk_solution_get_rank_domain_size": (idx_t, [_H, _S]),
+    "yk_solution_set_overall_domain_size": (C.c_int, [_H, _S, idx_t]),
+    "yk_solution_get_overall_domain_size": (idx_t, [_H, _S]),
+    "yk_solution_set_block_size": (C.c_int, [_H, _S, idx_t]),
+    "yk_solution_get_block_size": (idx_t, [_H, _S]),
+    "yk_solution_set_num_ranks": (C.c_int, [_H, _S, idx_t]),
+    "yk_solution_get_num_ranks": (idx_t, [_H, _S]),
+    "yk_solution_set_rank_index": (C.c_int, [_H, _S, idx_t]),
+    "yk_solution_get_rank_index": (idx_t, [_H, _S]),
+    "yk_solution_apply_command_line_options": (C.c_int, [_H, _S, C.c_char_p, C.c_size_t]),
+    "yk_solution_get_command_line_help": (_S, [_H]),
+    "yk_solution_get_command_line_values": (_S, [_H]),
+    "yk_solution_get_num_vars": (C.c_int, [_H]),
+    "yk_solution_get_var": (_H, [_H, _S]),
+    "yk_solution_get_var_by_index": (_H, [_H, C.c_int]),
+    "yk_solution_prepare": (C.c_int, [_H]),
+    "yk_solution_get_first_rank_domain_index": (idx_t, [_H, _S]),
+    "yk_solution_get_last_rank_domain_index": (idx_t, [_H, _S]),
+    "yk_solution_run": (C.c_int, [_H, idx_t, idx_t]),
+    "yk_solution_end": (C.c_int, [_H]),
+    "yk_solution_exchange_halos": (C.c_int, [_H]),
+    "yk_solution_copy_vars_to_device": (C.c_int, [_H]),
+    "yk_solution_copy_vars_from_device": (C.c_int, [_H]),
+    "yk_solution_get_stats": (C.c_int, [_H, C.POINTER(YkStats)]),
+    "yk_solution_reset_auto_tuner": (C.c_int, [_H, C.c_int, C.c_int]),
+    "yk_solution_is_auto_tuner_enabled": (C.c_int, [_H]),
+    "yk_solution_run_auto_tuner_now": (C.c_int, [_H, C.c_int]),
+    "yk_solution_new_var": (_H, [_H, _S, C.c_int, C.POINTER(C.c_char_p)]),
+    "yk_solution_new_fixed_size_var": (_H, [_H, _S, C.c_int, C.POINTER(C.c_char_p), _IP]),
+    "yk_solution_compare_data": (idx_t, [_H, _H, C.c_double]),
+    "yk_solution_set_streams": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    "yk_solution_get_kernel_variant": (_S, [_H, C.c_int]),
+    "yk_solution_get_num_kernel_variants": (C.c_int, [_H, C.c_int]),
+    "yk_solution_get_kernel_variant_name": (_S, [_H, C.c_int, C.c_int]),
+    "yk_solution_time_part": (C.c_int, [_H, C.c_int, C.c_int, idx_t, idx_t, C.c_int, C.POINTER(C.c_float)]),
+    "yk_var_get_name": (_S, [_H]),
+    "yk_var_get_num_dims": (C.c_int, [_H]),
+    "yk_var_get_dim_name": (_S, [_H, C.c_int]),
+    "yk_var_is_dim_used": (C.c_int, [_H, _S]),
+    "yk_var_is_fixed_size": (C.c_int, [_H]),
+    "yk_var_get_first_local_index": (idx_t, [_H, _S]),
+    "yk_var_get_last_local_index": (idx_t, [_H, _S]),
+    "yk_var_get_alloc_size": (idx_t, [_H, _S]),
+    "yk_var_get_first_valid_step_index": (idx_t, [_H]),
+    "yk_var_get_last_valid_step_index": (idx_t, [_H]),
+    "yk_var_get_rank_domain_size": (idx_t, [_H, _S]),
+    "yk_var_get_first_rank_domain_index": (idx_t, [_H, _S]),
+    "yk_var_get_last_rank_domain_index": (idx_t, [_H, _S]),
+    "yk_var_get_left_halo_size": (idx_t, [_H, _S]),
+    "yk_var_get_right_halo_size": (idx_t, [_H, _S]),
+    "yk_var_get_first_rank_halo_index": (idx_t, [_H, _S]),
+    "yk_var_get_last_rank_halo_index": (idx_t, [_H, _S]),
+    "yk_var_get_left_pad_size": (idx_t, [_H, _S]),
+    "yk_var_get_right_pad_size": (idx_t, [_H, _S]),
+    "yk_var_get_left_extra_pad_size": (idx_t, [_H, _S]),
+    "yk_var_get_right_extra_pad_size": (idx_t, [_H, _S]),
+    "yk_var_get_first_misc_index": (idx_t, [_H, _S]),
+    "yk_var_get_last_misc_index": (idx_t, [_H, _S]),
+    "yk_var_set_left_min_pad_size": (C.c_int, [_H, _S, idx_t]),
+    "yk_var_set_right_min_pad_size": (C.c_int, [_H, _S, idx_t]),
+    "yk_var_set_min_pad_size": (C.c_int, [_H, _S, idx_t]),
+    "yk_var_set_left_halo_size": (C.c_int, [_H, _S, idx_t]),
+    "yk_var_set_right_halo_size": (C.c_int, [_H, _S, idx_t]),
+    "yk_var_set_halo_size": (C.c_int, [_H, _S, idx_t]),
+    "yk_var_set_first_misc_index": (C.c_int, [_H, _S, idx_t]),
+    "yk_var_set_alloc_size": (C.c_int, [_H, _S, idx_t]),
+    "yk_var_are_indices_local": (C.c_int, [_H, _IP]),
+    "yk_var_get_element": (C.c_double, [_H, _IP]),
+    "yk_var_set_element": (idx_t, [_H, C.c_double, _IP, C.c_int]),
+    "yk_var_add_to_element": (idx_t, [_H, C.c_double, _IP, C.c_int]),
+    "yk_var_get_elements_in_slice_f32": (idx_t, [_H, C.c_void_p, C.c_size_t, _IP, _IP]),
+    "yk_var_get_elements_in_slice_f64": (idx_t, [_H, C.c_void_p, C.c_size_t, _IP, _IP]),
+    "yk_var_set_elements_in_slice_f32": (idx_t, [_H, C.c_void_p, C.c_size_t, _IP, _IP]),
+    "yk_var_set_elements_in_slice_f64": (idx_t, [_H, C.c_void_p, C.c_size_t, _IP, _IP]),
+    "yk_var_set_elements_in_slice_same": (idx_t, [_H, C.c_double, _IP, _IP, C.c_int]),
+    "yk_var_set_all_elements_same": (C.c_int, [_H, C.c_double]),
+    "yk_var_reduce_elements_in_slice": (C.c_int, [_H, C.c_int, _IP, _IP, C.c_int, C.POINTER(YkReduction)]),
+    "yk_var_get_halo_exchange_l1_norm": (C.c_int, [_H]),
+    "yk_var_set_halo_exchange_l1_norm": (C.c_int, [_H, C.c_int]),
+    "yk_var_is_dynamic_step_alloc": (C.c_int, [_H]),
+    "yk_var_is_storage_allocated": (C.c_int, [_H]),
+    "yk_var_get_num_storage_bytes": (idx_t, [_H]),
+    "yk_var_get_num_storage_elements": (idx_t, [_H]),
+    "yk_var_alloc_storage": (C.c_int, [_H]),
+    "yk_var_release_storage": (C.c_int, [_H]),
+    "yk_var_is_storage_layout_identical": (C.c_int, [_H, _H]),
+    "yk_var_fuse_vars": (C.c_int, [_H, _H]),
+    "yk_var_get_raw_storage_buffer": (C.c_void_p, [_H]),
+    "yk_var_sync_raw_storage_to_device": (C.c_int, [_H]),
+    "yk_var_get_device_storage": (C.c_void_p, [_H]),
+    "yk_var_set_elements_hash": (C.c_int, [_H, C.c_double, C.c_double, C.c_int]),
+}
+
+
+def header_symbols() -> list[str]:
+    """Names of all functions declared in include/yask_hip_c_api.h."""
+    txt = HEADER.read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(yk_[a-z0-9_]+)\s*\(", txt)) - {"yk_exchange_fn", "yk_allreduce_fn"})
+
+
+def lib_path(stencil: str) -> Path:
+    return LIB_DIR / f"libyask_kernel.{stencil}.cdna4_hip.so"
+
+
+_loaded: dict[str, C.CDLL] = {}
+
+
+def load(stencil: str) -> C.CDLL:
+    """dlopen the stencil's kernel library and attach prototypes. Raises if it is not built."""
+    if stencil in _loaded:
+        return _loaded[stencil]
+    p = lib_path(stencil)
+    if not p.exists():
+        raise ImportError(
+            f"{p} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            f"`make -C yask_amd/csrc STENCILS={stencil}` (hipcc, --offload-arch=gfx950). "
+            "There is no CPU fallback for the cdna4_hip kernel library.")
+    lib = C.CDLL(str(p), mode=getattr(os, "RTLD_LOCAL", 0))
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)      # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _loaded[stencil] = lib
+    return lib

@@ -1,0 +1,524 @@
+// ykh_c_api.cpp -- extern "C" boundary of libyask_kernel.<stencil>.cdna4_hip.so
+// (declarations and reference citations: include/yask_hip_c_api.h). Exceptions never cross the
+// boundary: they are caught here and turned into an error code + yk_last_error().
+#include "../../include/yask_hip_c_api.h"
+
+#include <cstring>
+#include <sstream>
+
+#include "ykh_handles.hpp"
+#include "ykh_runtime.hpp"
+
+using namespace ykh;
+
+static thread_local std::string g_err;
+static thread_local int g_err_code = 0;
+
+#define YK_TRY g_err_code = 0; try {
+#define YK_CATCH(retval)                                                           \
+    } catch (const std::exception& e) { g_err = e.what(); g_err_code = 1; return retval; } \
+      catch (...) { g_err = "YASK error: unknown exception"; g_err_code = 1; return retval; }
+
+static Var* V(yk_var_h v) {
+    if (!v) YKH_THROW("null var handle");
+    return reinterpret_cast<Var*>(v);
+}
+static Solution& S(yk_soln_h s) {
+    if (!s || !s->soln) YKH_THROW("null solution handle");
+    return *s->soln;
+}
+static std::vector<idx_t> vec(Var* v, const yk_idx_t* p) {
+    if (!p) YKH_THROW("null index array");
+    return std::vector<idx_t>(p, p + v->dims.size());
+}
+static int dom(Var* v, const char* dim, const char* fn) {
+    int p = v->dim_posn(dim);
+    if (v->dims[p].type != DIM_DOMAIN)
+        YKH_THROW(std::string(fn) + ": dimension '" + dim + "' of var '" + v->name + "' is not a domain dimension");
+    return v->dims[p].domain_idx;
+}
+
+extern "C" {
+
+const char* yk_last_error(void) { return g_err.c_str(); }
+int yk_last_error_code(void) { return g_err_code; }
+void yk_clear_error(void) { g_err.clear(); g_err_code = 0; }
+
+const char* yk_get_version_string(void) { static std::string v = version_string(); return v.c_str(); }
+
+yk_env_h yk_new_env(void) {
+    YK_TRY
+    auto* e = new yk_env_s;
+    e->env = std::make_shared<Env>();
+    return e;
+    YK_CATCH(nullptr)
+}
+void yk_free_env(yk_env_h env) { delete env; }
+
+yk_soln_h yk_new_solution(yk_env_h env) {
+    YK_TRY
+    if (!env) YKH_THROW("null env handle");
+    auto* s = new yk_solution_s;
+    s->soln = std::make_shared<Solution>(env->env, ykh_solution_impl());
+    return s;
+    YK_CATCH(nullptr)
+}
+yk_soln_h yk_new_solution_from(yk_env_h env, yk_soln_h source) {
+    YK_TRY
+    yk_soln_h s = yk_new_solution(env);
+    if (!s) return nullptr;
+    Solution& d = *s->soln;
+    Solution& o = S(source);
+    for (int i = 0; i < MAX_DOMAIN_DIMS; i++) {
+        d.global_size[i] = o.global_size[i]; d.rank_size[i] = o.rank_size[i];
+        d.num_ranks[i] = o.num_ranks[i]; d.rank_index[i] = o.rank_index[i];
+        d.min_pad[i] = o.min_pad[i]; d.extra_pad[i] = o.extra_pad[i];
+    }
+    for (int i = 0; i <= MAX_DOMAIN_DIMS; i++) d.block_size[i] = o.block_size[i];
+    d.rank_index_set = o.rank_index_set;
+    d.overlap_comms = o.overlap_comms; d.min_exterior = o.min_exterior; d.do_halo_exchange = o.do_halo_exchange;
+    d.auto_tune = o.auto_tune; d.force_scalar = o.force_scalar; d.variant_override = o.variant_override;
+    d.xchunk_override = o.xchunk_override;
+    return s;
+    YK_CATCH(nullptr)
+}
+void yk_free_solution(yk_soln_h s) { delete s; }
+
+int yk_env_get_num_ranks(yk_env_h e) { return e ? e->env->nranks : 0; }
+int yk_env_get_rank_index(yk_env_h e) { return e ? e->env->rank : 0; }
+int yk_env_global_barrier(yk_env_h e) {
+    YK_TRY
+    if (!e) YKH_THROW("null env handle");
+    (void)e->env->sum_over_ranks(0);
+    return 0;
+    YK_CATCH(1)
+}
+yk_idx_t yk_env_sum_over_ranks(yk_env_h e, yk_idx_t v) {
+    YK_TRY
+    if (!e) YKH_THROW("null env handle");
+    return e->env->sum_over_ranks(v);
+    YK_CATCH(0)
+}
+void yk_env_set_trace_enabled(yk_env_h e, int en) { if (e) e->env->trace = en != 0; }
+int yk_env_set_ranks(yk_env_h e, int rank, int n) {
+    YK_TRY
+    if (!e) YKH_THROW("null env handle");
+    e->env->set_ranks(rank, n);
+    return 0;
+    YK_CATCH(1)
+}
+int yk_env_set_transport(yk_env_h e, yk_exchange_fn start, yk_exchange_fn wait, yk_allreduce_fn ar, void* user) {
+    YK_TRY
+    if (!e) YKH_THROW("null env handle");
+    static_assert(sizeof(yk_halo_msg) == sizeof(HaloMsg), "yk_halo_msg must mirror ykh::HaloMsg");
+    e->env->exch_start = reinterpret_cast<ykh_exchange_fn>(start);
+    e->env->exch_wait = reinterpret_cast<ykh_exchange_fn>(wait);
+    e->env->allreduce = ar;
+    e->env->user = user;
+    return 0;
+    YK_CATCH(1)
+}
+
+// ---- solution
+const char* yk_solution_get_name(yk_soln_h s) { return s ? s->soln->meta->name : ""; }
+const char* yk_solution_get_description(yk_soln_h s) { return s ? s->soln->meta->description : ""; }
+const char* yk_solution_get_target(yk_soln_h s) { return s ? s->soln->meta->target : ""; }
+int yk_solution_is_offloaded(yk_soln_h) { return 1; }
+int yk_solution_get_element_bytes(yk_soln_h s) { return s ? s->soln->meta->elem_bytes : 0; }
+const char* yk_solution_get_step_dim_name(yk_soln_h s) { return s ? s->soln->step_dim_name.c_str() : ""; }
+int yk_solution_get_num_domain_dims(yk_soln_h s) { return s ? s->soln->ndd : 0; }
+const char* yk_solution_get_domain_dim_name(yk_soln_h s, int i) {
+    YK_TRY
+    Solution& so = S(s);
+    if (i < 0 || i >= so.ndd) YKH_THROW("domain-dim index out of range");
+    return so.domain_dim_names[i].c_str();
+    YK_CATCH("")
+}
+int yk_solution_get_num_misc_dims(yk_soln_h s) { return s ? (int)s->soln->misc_dim_names.size() : 0; }
+const char* yk_solution_get_misc_dim_name(yk_soln_h s, int i) {
+    YK_TRY
+    Solution& so = S(s);
+    if (i < 0 || i >= (int)so.misc_dim_names.size()) YKH_THROW("misc-dim index out of range");
+    return so.misc_dim_names[i].c_str();
+    YK_CATCH("")
+}
+
+#define SOLN_SET(NAME, BODY)                                                   \
+    int NAME(yk_soln_h s, const char* dim, yk_idx_t n) {                       \
+        YK_TRY                                                                 \
+        Solution& so = S(s);                                                   \
+        BODY;                                                                  \
+        return 0;                                                              \
+        YK_CATCH(1)                                                            \
+    }
+#define SOLN_GET(NAME, EXPR)                                                   \
+    yk_idx_t NAME(yk_soln_h s, const char* dim) {                              \
+        YK_TRY                                                                 \
+        Solution& so = S(s);                                                   \
+        return (EXPR);                                                         \
+        YK_CATCH(0)                                                            \
+    }
+// Setting a size after prepare_solution() clears "prepared" (soln_apis.cpp:47-57,86-103).
+SOLN_SET(yk_solution_set_rank_domain_size, { int d = so.domain_dim_idx(dim, "set_rank_domain_size"); so.rank_size[d] = n; if (n) so.global_size[d] = 0; so.invalidate(); })
+SOLN_GET(yk_solution_get_rank_domain_size, so.prepared ? so.local_size[so.domain_dim_idx(dim, "get_rank_domain_size")] : so.rank_size[so.domain_dim_idx(dim, "get_rank_domain_size")])
+SOLN_SET(yk_solution_set_overall_domain_size, { int d = so.domain_dim_idx(dim, "set_overall_domain_size"); so.global_size[d] = n; if (n) so.rank_size[d] = 0; so.invalidate(); })
+SOLN_GET(yk_solution_get_overall_domain_size, so.global_size[so.domain_dim_idx(dim, "get_overall_domain_size")])
+SOLN_SET(yk_solution_set_num_ranks, { so.num_ranks[so.domain_dim_idx(dim, "set_num_ranks")] = n; so.invalidate(); })
+SOLN_GET(yk_solution_get_num_ranks, so.num_ranks[so.domain_dim_idx(dim, "get_num_ranks")])
+SOLN_SET(yk_solution_set_rank_index, { so.rank_index[so.domain_dim_idx(dim, "set_rank_index")] = n; so.rank_index_set = true; so.invalidate(); })
+SOLN_GET(yk_solution_get_rank_index, so.rank_index[so.domain_dim_idx(dim, "get_rank_index")])
+
+int yk_solution_set_block_size(yk_soln_h s, const char* dim, yk_idx_t n) {
+    YK_TRY
+    Solution& so = S(s);
+    if (so.step_dim_name == dim) so.block_size[0] = n;
+    else so.block_size[1 + so.domain_dim_idx(dim, "set_block_size")] = n;
+    return 0;
+    YK_CATCH(1)
+}
+yk_idx_t yk_solution_get_block_size(yk_soln_h s, const char* dim) {
+    YK_TRY
+    Solution& so = S(s);
+    if (so.step_dim_name == dim) return so.block_size[0];
+    return so.block_size[1 + so.domain_dim_idx(dim, "get_block_size")];
+    YK_CATCH(0)
+}
+
+int yk_solution_apply_command_line_options(yk_soln_h s, const char* args, char* rem, size_t cap) {
+    YK_TRY
+    Solution& so = S(s);
+    std::vector<std::string> toks;
+    std::istringstream is(args ? args : "");
+    std::string t;
+    while (is >> t) toks.push_back(t);
+    std::string r = so.apply_command_line_options(toks);
+    if (rem && cap) { std::strncpy(rem, r.c_str(), cap - 1); rem[cap - 1] = 0; }
+    return 0;
+    YK_CATCH(1)
+}
+const char* yk_solution_get_command_line_help(yk_soln_h s) {
+    YK_TRY
+    s->help = S(s).get_command_line_help();
+    return s->help.c_str();
+    YK_CATCH("")
+}
+const char* yk_solution_get_command_line_values(yk_soln_h s) {
+    YK_TRY
+    s->values = S(s).get_command_line_values();
+    return s->values.c_str();
+    YK_CATCH("")
+}
+int yk_solution_get_num_vars(yk_soln_h s) { return s ? (int)s->soln->vars.size() : 0; }
+yk_var_h yk_solution_get_var(yk_soln_h s, const char* name) {
+    YK_TRY
+    return reinterpret_cast<yk_var_h>(S(s).get_var(name ? name : "").get());
+    YK_CATCH(nullptr)
+}
+yk_var_h yk_solution_get_var_by_index(yk_soln_h s, int i) {
+    YK_TRY
+    Solution& so = S(s);
+    if (i < 0 || i >= (int)so.vars.size()) YKH_THROW("var index out of range");
+    return reinterpret_cast<yk_var_h>(so.vars[i].get());
+    YK_CATCH(nullptr)
+}
+int yk_solution_prepare(yk_soln_h s) { YK_TRY S(s).prepare(); return 0; YK_CATCH(1) }
+yk_idx_t yk_solution_get_first_rank_domain_index(yk_soln_h s, const char* dim) {
+    YK_TRY
+    Solution& so = S(s);
+    return so.rank_ofs[so.domain_dim_idx(dim, "get_first_rank_domain_index")];
+    YK_CATCH(0)
+}
+yk_idx_t yk_solution_get_last_rank_domain_index(yk_soln_h s, const char* dim) {
+    YK_TRY
+    Solution& so = S(s);
+    int d = so.domain_dim_idx(dim, "get_last_rank_domain_index");
+    return so.rank_ofs[d] + so.local_size[d] - 1;
+    YK_CATCH(0)
+}
+int yk_solution_run(yk_soln_h s, yk_idx_t a, yk_idx_t b) { YK_TRY S(s).run(a, b); return 0; YK_CATCH(1) }
+int yk_solution_end(yk_soln_h s) { YK_TRY S(s).end(); return 0; YK_CATCH(1) }
+int yk_solution_exchange_halos(yk_soln_h s) { YK_TRY S(s).exchange_halos_all(); S(s).synchronize(); return 0; YK_CATCH(1) }
+int yk_solution_copy_vars_to_device(yk_soln_h s) { YK_TRY S(s).copy_vars_to_device(); return 0; YK_CATCH(1) }
+int yk_solution_copy_vars_from_device(yk_soln_h s) { YK_TRY S(s).copy_vars_from_device(); return 0; YK_CATCH(1) }
+int yk_solution_get_stats(yk_soln_h s, yk_stats_t* out) {
+    YK_TRY
+    if (!out) YKH_THROW("null stats pointer");
+    Stats st = S(s).get_stats();
+    out->num_elements = st.num_elements; out->num_steps_done = st.num_steps_done;
+    out->num_writes_done = st.num_writes_done; out->est_fp_ops_done = st.est_fp_ops_done;
+    out->elapsed_secs = st.elapsed_secs; out->num_reads_done = st.num_reads_done;
+    out->halo_secs = st.halo_secs; out->points_per_sec = st.pts_per_sec;
+    return 0;
+    YK_CATCH(1)
+}
+int yk_solution_reset_auto_tuner(yk_soln_h s, int enable, int) { YK_TRY S(s).reset_auto_tuner(enable != 0); return 0; YK_CATCH(1) }
+int yk_solution_is_auto_tuner_enabled(yk_soln_h s) { return s && s->soln->auto_tune ? 1 : 0; }
+int yk_solution_run_auto_tuner_now(yk_soln_h s, int verbose) {
+    YK_TRY
+    Solution& so = S(s);
+    bool old = so.env->trace;
+    if (verbose) so.env->trace = true;
+    so.run_auto_tuner_now();
+    so.env->trace = old;
+    return 0;
+    YK_CATCH(1)
+}
+yk_var_h yk_solution_new_var(yk_soln_h s, const char* name, int nd, const char* const* dims) {
+    YK_TRY
+    std::vector<std::string> d;
+    for (int i = 0; i < nd; i++) d.push_back(dims[i]);
+    return reinterpret_cast<yk_var_h>(S(s).new_var(name, d).get());
+    YK_CATCH(nullptr)
+}
+yk_var_h yk_solution_new_fixed_size_var(yk_soln_h s, const char* name, int nd, const char* const* dims,
+                                        const yk_idx_t* sizes) {
+    YK_TRY
+    std::vector<std::string> d;
+    std::vector<idx_t> sz;
+    for (int i = 0; i < nd; i++) { d.push_back(dims[i]); sz.push_back(sizes[i]); }
+    return reinterpret_cast<yk_var_h>(S(s).new_fixed_size_var(name, d, sz).get());
+    YK_CATCH(nullptr)
+}
+yk_idx_t yk_solution_compare_data(yk_soln_h s, yk_soln_h ref, double eps) {
+    YK_TRY
+    return S(s).compare_data(S(ref), eps);
+    YK_CATCH(-1)
+}
+int yk_solution_set_streams(yk_soln_h s, void* c, void* m) {
+    YK_TRY S(s).set_streams((hipStream_t)c, (hipStream_t)m); return 0; YK_CATCH(1)
+}
+const char* yk_solution_get_kernel_variant(yk_soln_h s, int part) {
+    YK_TRY
+    Solution& so = S(s);
+    if (part < 0 || part >= (int)so.impl.parts.size()) YKH_THROW("part index out of range");
+    int v = so.part_variant[part];
+    if (v < 0) v = so.impl.parts[part].default_variant;
+    std::ostringstream os;
+    os << so.impl.parts[part].variants[v].name;
+    s->variant = os.str();
+    return s->variant.c_str();
+    YK_CATCH("")
+}
+int yk_solution_get_num_kernel_variants(yk_soln_h s, int part) {
+    YK_TRY
+    Solution& so = S(s);
+    if (part < 0 || part >= (int)so.impl.parts.size()) YKH_THROW("part index out of range");
+    return (int)so.impl.parts[part].variants.size();
+    YK_CATCH(0)
+}
+const char* yk_solution_get_kernel_variant_name(yk_soln_h s, int part, int i) {
+    YK_TRY
+    Solution& so = S(s);
+    if (part < 0 || part >= (int)so.impl.parts.size()) YKH_THROW("part index out of range");
+    if (i < 0 || i >= (int)so.impl.parts[part].variants.size()) YKH_THROW("variant index out of range");
+    return so.impl.parts[part].variants[i].name;
+    YK_CATCH("")
+}
+int yk_solution_time_part(yk_soln_h s, int part, int variant, yk_idx_t xchunk, yk_idx_t t, int reps, float* ms) {
+    YK_TRY
+    Solution& so = S(s);
+    if (!so.prepared) YKH_THROW("yk_solution_time_part() called without calling prepare_solution() first");
+    if (part < 0 || part >= (int)so.impl.parts.size()) YKH_THROW("part index out of range");
+    if (variant < 0) { variant = so.part_variant[part]; if (xchunk <= 0) xchunk = so.part_xchunk[part]; }
+    if (variant >= (int)so.impl.parts[part].variants.size()) YKH_THROW("variant index out of range");
+    hipEvent_t e0, e1;
+    YKH_HIP(hipEventCreate(&e0));
+    YKH_HIP(hipEventCreate(&e1));
+    Box rb = so.rank_box();
+    YKH_HIP(hipEventRecord(e0, so.compute_stream));
+    for (int i = 0; i < reps; i++) so.launch_part_variant(part, variant, xchunk, t + i, rb, so.compute_stream);
+    YKH_HIP(hipEventRecord(e1, so.compute_stream));
+    YKH_HIP(hipEventSynchronize(e1));
+    float m = 0;
+    YKH_HIP(hipEventElapsedTime(&m, e0, e1));
+    if (ms) *ms = m / (reps > 0 ? reps : 1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+    YK_CATCH(1)
+}
+
+// ---- var
+const char* yk_var_get_name(yk_var_h v) { return v ? reinterpret_cast<Var*>(v)->name.c_str() : ""; }
+int yk_var_get_num_dims(yk_var_h v) { return v ? (int)reinterpret_cast<Var*>(v)->dims.size() : 0; }
+const char* yk_var_get_dim_name(yk_var_h v, int i) {
+    YK_TRY
+    Var* x = V(v);
+    if (i < 0 || i >= (int)x->dims.size()) YKH_THROW("dim index out of range");
+    return x->dims[i].name.c_str();
+    YK_CATCH("")
+}
+int yk_var_is_dim_used(yk_var_h v, const char* dim) { YK_TRY return V(v)->dim_posn(dim, false) >= 0 ? 1 : 0; YK_CATCH(0) }
+int yk_var_is_fixed_size(yk_var_h v) { YK_TRY return V(v)->fixed_size ? 1 : 0; YK_CATCH(0) }
+
+#define VAR_GET(NAME, EXPR)                                  \
+    yk_idx_t NAME(yk_var_h v, const char* dim) {             \
+        YK_TRY                                               \
+        Var* x = V(v);                                       \
+        (void)dim;                                           \
+        return (EXPR);                                       \
+        YK_CATCH(0)                                          \
+    }
+VAR_GET(yk_var_get_first_local_index, x->first_local_index(x->dim_posn(dim)))
+VAR_GET(yk_var_get_last_local_index, x->last_local_index(x->dim_posn(dim)))
+VAR_GET(yk_var_get_alloc_size, x->alloc_size(x->dim_posn(dim)))
+yk_idx_t yk_var_get_first_valid_step_index(yk_var_h v) {
+    YK_TRY
+    Var* x = V(v);
+    if (!x->has_step) YKH_THROW("'get_first_valid_step_index' called on var '" + x->name + "' that does not use the step dimension");
+    return x->first_valid_step;
+    YK_CATCH(0)
+}
+yk_idx_t yk_var_get_last_valid_step_index(yk_var_h v) {
+    YK_TRY
+    Var* x = V(v);
+    if (!x->has_step) YKH_THROW("'get_last_valid_step_index' called on var '" + x->name + "' that does not use the step dimension");
+    return x->last_valid_step();
+    YK_CATCH(0)
+}
+VAR_GET(yk_var_get_rank_domain_size, x->dom_size[dom(x, dim, "get_rank_domain_size")])
+VAR_GET(yk_var_get_first_rank_domain_index, x->rank_ofs[dom(x, dim, "get_first_rank_domain_index")])
+VAR_GET(yk_var_get_last_rank_domain_index, x->rank_ofs[dom(x, dim, "get_last_rank_domain_index")] + x->dom_size[dom(x, dim, "get_last_rank_domain_index")] - 1)
+VAR_GET(yk_var_get_left_halo_size, x->halo_l[dom(x, dim, "get_left_halo_size")])
+VAR_GET(yk_var_get_right_halo_size, x->halo_r[dom(x, dim, "get_right_halo_size")])
+VAR_GET(yk_var_get_first_rank_halo_index, x->rank_ofs[dom(x, dim, "get_first_rank_halo_index")] - x->halo_l[dom(x, dim, "get_first_rank_halo_index")])
+VAR_GET(yk_var_get_last_rank_halo_index, x->rank_ofs[dom(x, dim, "get_last_rank_halo_index")] + x->dom_size[dom(x, dim, "get_last_rank_halo_index")] + x->halo_r[dom(x, dim, "get_last_rank_halo_index")] - 1)
+VAR_GET(yk_var_get_left_pad_size, x->pad_l[dom(x, dim, "get_left_pad_size")])
+VAR_GET(yk_var_get_right_pad_size, x->pad_r[dom(x, dim, "get_right_pad_size")])
+VAR_GET(yk_var_get_left_extra_pad_size, x->pad_l[dom(x, dim, "get_left_extra_pad_size")] - x->halo_l[dom(x, dim, "get_left_extra_pad_size")])
+VAR_GET(yk_var_get_right_extra_pad_size, x->pad_r[dom(x, dim, "get_right_extra_pad_size")] - x->halo_r[dom(x, dim, "get_right_extra_pad_size")])
+yk_idx_t yk_var_get_first_misc_index(yk_var_h v, const char* dim) {
+    YK_TRY
+    Var* x = V(v);
+    int p = x->dim_posn(dim);
+    if (x->dims[p].type != DIM_MISC) YKH_THROW("get_first_misc_index: '" + std::string(dim) + "' is not a misc dimension of var '" + x->name + "'");
+    return x->dims[p].first_misc;
+    YK_CATCH(0)
+}
+yk_idx_t yk_var_get_last_misc_index(yk_var_h v, const char* dim) {
+    YK_TRY
+    Var* x = V(v);
+    int p = x->dim_posn(dim);
+    if (x->dims[p].type != DIM_MISC) YKH_THROW("get_last_misc_index: '" + std::string(dim) + "' is not a misc dimension of var '" + x->name + "'");
+    return x->dims[p].last_misc;
+    YK_CATCH(0)
+}
+
+#define VAR_SET(NAME, BODY)                                         \
+    int NAME(yk_var_h v, const char* dim, yk_idx_t n) {             \
+        YK_TRY                                                      \
+        Var* x = V(v);                                              \
+        BODY;                                                       \
+        return 0;                                                   \
+        YK_CATCH(1)                                                 \
+    }
+// changing geometry of a var with storage requires re-preparing the solution
+static void regeom(Var* x) {
+    if (x->fixed_size) { x->compute_geometry(); if (x->is_allocated()) x->allocate(); }
+    else x->soln->invalidate();
+}
+VAR_SET(yk_var_set_left_min_pad_size, { x->min_pad_l[dom(x, dim, "set_left_min_pad_size")] = n; regeom(x); })
+VAR_SET(yk_var_set_right_min_pad_size, { x->min_pad_r[dom(x, dim, "set_right_min_pad_size")] = n; regeom(x); })
+VAR_SET(yk_var_set_min_pad_size, { int d = dom(x, dim, "set_min_pad_size"); x->min_pad_l[d] = x->min_pad_r[d] = n; regeom(x); })
+VAR_SET(yk_var_set_left_halo_size, { x->halo_l[dom(x, dim, "set_left_halo_size")] = n; regeom(x); })
+VAR_SET(yk_var_set_right_halo_size, { x->halo_r[dom(x, dim, "set_right_halo_size")] = n; regeom(x); })
+VAR_SET(yk_var_set_halo_size, { int d = dom(x, dim, "set_halo_size"); x->halo_l[d] = x->halo_r[d] = n; regeom(x); })
+VAR_SET(yk_var_set_first_misc_index, {
+    int p = x->dim_posn(dim);
+    if (x->dims[p].type != DIM_MISC) YKH_THROW("set_first_misc_index: '" + std::string(dim) + "' is not a misc dimension");
+    idx_t sz = x->dims[p].last_misc - x->dims[p].first_misc;
+    x->dims[p].first_misc = n; x->dims[p].last_misc = n + sz;
+})
+VAR_SET(yk_var_set_alloc_size, {
+    int p = x->dim_posn(dim);
+    if (n < 1) YKH_THROW("set_alloc_size: size must be positive");
+    if (x->dims[p].type == DIM_DOMAIN) YKH_THROW("set_alloc_size: cannot set the allocation of domain dimension '" + std::string(dim) + "'; use the pad-size calls");
+    if (x->dims[p].type == DIM_STEP) {
+        if (!x->dynamic_step_alloc) YKH_THROW("set_alloc_size: var '" + x->name + "' does not allow dynamic step allocation");
+        x->nslots = (int)n; x->dirty.assign(n, 1);
+    } else x->dims[p].last_misc = x->dims[p].first_misc + n - 1;
+    regeom(x);
+})
+
+int yk_var_are_indices_local(yk_var_h v, const yk_idx_t* idx) { YK_TRY Var* x = V(v); return x->indices_local(vec(x, idx)) ? 1 : 0; YK_CATCH(0) }
+double yk_var_get_element(yk_var_h v, const yk_idx_t* idx) { YK_TRY Var* x = V(v); return x->get_element(vec(x, idx)); YK_CATCH(0.0) }
+yk_idx_t yk_var_set_element(yk_var_h v, double val, const yk_idx_t* idx, int strict) {
+    YK_TRY Var* x = V(v); return x->set_element(val, vec(x, idx), strict != 0); YK_CATCH(0)
+}
+yk_idx_t yk_var_add_to_element(yk_var_h v, double val, const yk_idx_t* idx, int strict) {
+    YK_TRY Var* x = V(v); return x->add_to_element(val, vec(x, idx), strict != 0); YK_CATCH(0)
+}
+yk_idx_t yk_var_get_elements_in_slice_f32(yk_var_h v, float* buf, size_t n, const yk_idx_t* f, const yk_idx_t* l) {
+    YK_TRY Var* x = V(v); return x->get_elements_in_slice(buf, n, 4, vec(x, f), vec(x, l)); YK_CATCH(0)
+}
+yk_idx_t yk_var_get_elements_in_slice_f64(yk_var_h v, double* buf, size_t n, const yk_idx_t* f, const yk_idx_t* l) {
+    YK_TRY Var* x = V(v); return x->get_elements_in_slice(buf, n, 8, vec(x, f), vec(x, l)); YK_CATCH(0)
+}
+yk_idx_t yk_var_set_elements_in_slice_f32(yk_var_h v, const float* buf, size_t n, const yk_idx_t* f, const yk_idx_t* l) {
+    YK_TRY Var* x = V(v); return x->set_elements_in_slice(buf, n, 4, vec(x, f), vec(x, l)); YK_CATCH(0)
+}
+yk_idx_t yk_var_set_elements_in_slice_f64(yk_var_h v, const double* buf, size_t n, const yk_idx_t* f, const yk_idx_t* l) {
+    YK_TRY Var* x = V(v); return x->set_elements_in_slice(buf, n, 8, vec(x, f), vec(x, l)); YK_CATCH(0)
+}
+yk_idx_t yk_var_set_elements_in_slice_same(yk_var_h v, double val, const yk_idx_t* f, const yk_idx_t* l, int strict) {
+    YK_TRY Var* x = V(v); return x->set_elements_in_slice_same(val, vec(x, f), vec(x, l), strict != 0); YK_CATCH(0)
+}
+int yk_var_set_all_elements_same(yk_var_h v, double val) { YK_TRY V(v)->set_all_elements_same(val); return 0; YK_CATCH(1) }
+int yk_var_reduce_elements_in_slice(yk_var_h v, int mask, const yk_idx_t* f, const yk_idx_t* l, int strict, yk_reduction_t* out) {
+    YK_TRY
+    Var* x = V(v);
+    if (!out) YKH_THROW("null reduction pointer");
+    Var::Reduction r = x->reduce_elements_in_slice(mask, vec(x, f), vec(x, l), strict != 0);
+    out->reduction_mask = mask; out->num_elements_reduced = r.n;
+    out->sum = r.sum; out->sum_squares = r.sum_sq; out->product = r.prod; out->max = r.vmax; out->min = r.vmin;
+    return 0;
+    YK_CATCH(1)
+}
+int yk_var_get_halo_exchange_l1_norm(yk_var_h v) { YK_TRY return V(v)->l1_norm; YK_CATCH(0) }
+int yk_var_set_halo_exchange_l1_norm(yk_var_h v, int n) { YK_TRY V(v)->l1_norm = n; V(v)->soln->invalidate(); return 0; YK_CATCH(1) }
+int yk_var_is_dynamic_step_alloc(yk_var_h v) { YK_TRY return V(v)->dynamic_step_alloc ? 1 : 0; YK_CATCH(0) }
+int yk_var_is_storage_allocated(yk_var_h v) { YK_TRY return V(v)->is_allocated() ? 1 : 0; YK_CATCH(0) }
+yk_idx_t yk_var_get_num_storage_bytes(yk_var_h v) { YK_TRY return (yk_idx_t)V(v)->bytes(); YK_CATCH(0) }
+yk_idx_t yk_var_get_num_storage_elements(yk_var_h v) { YK_TRY Var* x = V(v); return x->slot_elems * x->nslots; YK_CATCH(0) }
+int yk_var_alloc_storage(yk_var_h v) {
+    YK_TRY
+    Var* x = V(v);
+    if (!x->is_allocated()) { x->compute_geometry(); x->allocate(); }
+    return 0;
+    YK_CATCH(1)
+}
+int yk_var_release_storage(yk_var_h v) { YK_TRY V(v)->release(); return 0; YK_CATCH(1) }
+int yk_var_is_storage_layout_identical(yk_var_h v, yk_var_h o) {
+    YK_TRY
+    Var *a = V(v), *b = V(o);
+    if (a->dims.size() != b->dims.size() || a->slot_elems != b->slot_elems || a->nslots != b->nslots) return 0;
+    for (size_t i = 0; i < a->dims.size(); i++)
+        if (a->dims[i].name != b->dims[i].name) return 0;
+    for (int d = 0; d < MAX_DOMAIN_DIMS; d++)
+        if (a->stride[d] != b->stride[d] || a->pad_l[d] != b->pad_l[d] || a->dom_size[d] != b->dom_size[d]) return 0;
+    return 1;
+    YK_CATCH(0)
+}
+// fuse_vars (yk_var_api.hpp:1395): make `v` hold the data of `source`. Storage here is device memory
+// owned by one var, so the fuse is a device-to-device copy when layouts match (shared ownership of one
+// allocation is not supported on the device path yet).
+int yk_var_fuse_vars(yk_var_h v, yk_var_h src) {
+    YK_TRY
+    Var *a = V(v), *b = V(src);
+    if (!yk_var_is_storage_layout_identical(v, src)) YKH_THROW("fuse_vars: storage layouts of '" + a->name + "' and '" + b->name + "' differ");
+    if (!b->is_allocated()) { a->release(); return 0; }
+    if (!a->is_allocated()) a->allocate();
+    YKH_HIP(hipMemcpy(a->dptr, b->dptr, a->bytes(), hipMemcpyDeviceToDevice));
+    a->first_valid_step = b->first_valid_step;
+    a->set_dirty_all(true);
+    return 0;
+    YK_CATCH(1)
+}
+void* yk_var_get_raw_storage_buffer(yk_var_h v) { YK_TRY return V(v)->host_mirror(); YK_CATCH(nullptr) }
+int yk_var_sync_raw_storage_to_device(yk_var_h v) { YK_TRY V(v)->sync_mirror_to_device(); return 0; YK_CATCH(1) }
+void* yk_var_get_device_storage(yk_var_h v) { YK_TRY return V(v)->dptr; YK_CATCH(nullptr) }
+int yk_var_set_elements_hash(yk_var_h v, double offset, double scale, int id) {
+    YK_TRY V(v)->set_elements_hash(offset, scale, id); return 0; YK_CATCH(1)
+}
+
+}  // extern "C"

@@ -1,0 +1,450 @@
+// ykh_device.hpp -- hand-shaped CDNA4 (gfx950) kernel templates for YASK stencil parts.
+//
+// This is the MI355X replacement for the reference's generated `calc_vectors` nano/pico-block loop
+// (emitter src/compiler/lib/YaskKernel.cpp:591-719; device region D1 = `omp target teams
+// distribute` over nano-blocks, src/kernel/Makefile:539-563) and of the masked peel/remainder
+// machinery of StencilPartTmpl::calc_nano_block_opt (src/kernel/lib/stencil_calc.hpp:444-860),
+// which on a GPU collapses to bounds predicates.
+//
+// A stencil *part* (struct emitted by the `cdna4_hip` compiler target, see gen/*.hpp) provides
+//   - access groups (one base pointer per distinct (var, step-offset)),
+//   - the list of read offsets, and
+//   - `eval(A&)`: the equations, written against an accessor A with rd<g,dx,dy,dz>() / wr<g>().
+// Two kernel shapes instantiate it:
+//   naive_kernel   : one thread per point, every read is a (cached) global load. Always legal.
+//   star25d_kernel : 2.5-D blocking for axis-aligned ("star") reads of one group:
+//                    * a thread block owns a (y,z) tile and marches along x (the largest stride);
+//                    * x-neighbours live in a per-thread register queue (depth xlo+xhi+1);
+//                    * the centre plane (+ y/z halos) is staged in a double-buffered LDS slab; the
+//                      tile interior comes from the queue registers, only halos are re-read
+//                      from L2/HBM; y-neighbours are 16-byte LDS row reads, z-neighbours come
+//                      from a per-row register window assembled from 16-byte LDS reads;
+//                    * every global access is a 16-byte vector along the unit-stride dim z, and a
+//                      wavefront (64 lanes) covers 1-2 whole tile rows, so loads are coalesced
+//                      and the LDS reads are bank-conflict free;
+//                    * next-plane loads are issued before the barrier so HBM latency overlaps the
+//                      current plane's arithmetic.
+//   No MFMA: the update is ~3.8 flop/byte, bound by HBM.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include <utility>
+#include "ykh_meta.hpp"
+
+namespace ykh {
+
+// compile-time loop: f(integral_constant<int,0>) ... f(integral_constant<int,N-1>)
+template <class F, int... I>
+__host__ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__host__ __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// ------------------------------------------------------------------ vector types (16 B along z)
+template <typename T> struct vtraits;
+template <> struct vtraits<float> {
+    static constexpr int VZ = 4;
+    typedef float vec __attribute__((ext_vector_type(4)));
+};
+template <> struct vtraits<double> {
+    static constexpr int VZ = 2;
+    typedef double vec __attribute__((ext_vector_type(2)));
+};
+
+// ------------------------------------------------------------------ kernel arguments
+constexpr int MAX_GROUPS = 24;
+
+// All quantities are in *rank-local* element coordinates: index 0 is the first domain point of
+// this rank in each dim; halos/pads have negative indices or indices >= the local domain size.
+struct PartArgs {
+    void* ptr[MAX_GROUPS];        // per access group: address of local element (0,0,0) in the right step slot
+    idx_t gsx[MAX_GROUPS];        // per-group strides (0 for a dim the var does not have)
+    idx_t gsy[MAX_GROUPS];
+    int gsz[MAX_GROUPS];
+    idx_t sx, sy;                 // strides of the shared full-3D layout (all x,y,z vars use it)
+    int x0, x1, y0, y1, z0, z1;   // compute box [lo, hi)
+    int ax0, ax1, ay0, ay1, az0, az1;   // allocated extent [lo, hi) of the shared layout (load clamps)
+    int ntz, nty, nxc, xchunk;    // star25d tiling: tiles in z, y; chunks and chunk length in x
+    int ofs_x, ofs_y, ofs_z;      // global index of local 0 (rank offset), for index expressions
+    idx_t t;                      // evaluation step
+};
+
+// ------------------------------------------------------------------ compile-time read analysis
+struct StarRange {
+    int xlo, xhi, ylo, yhi, zlo, zhi;
+    bool mixed;      // some read has more than one non-zero offset
+    bool any;        // group is read at all
+    bool center;     // group is read at (0,0,0)
+};
+
+template <class P>
+constexpr StarRange analyze_group(int g) {
+    StarRange r = {0, 0, 0, 0, 0, 0, false, false, false};
+    for (int i = 0; i < P::n_reads; i++) {
+        if (P::reads[i].g != g) continue;
+        r.any = true;
+        int dx = P::reads[i].dx, dy = P::reads[i].dy, dz = P::reads[i].dz;
+        int nz = (dx != 0) + (dy != 0) + (dz != 0);
+        if (nz == 0) r.center = true;
+        if (nz > 1) { r.mixed = true; continue; }
+        if (dx < r.xlo) r.xlo = dx;
+        if (dx > r.xhi) r.xhi = dx;
+        if (dy < r.ylo) r.ylo = dy;
+        if (dy > r.yhi) r.yhi = dy;
+        if (dz < r.zlo) r.zlo = dz;
+        if (dz > r.zhi) r.zhi = dz;
+    }
+    return r;
+}
+
+// A part fits star25d when exactly one group has off-centre reads, none of them mixed, and every
+// var touched uses the shared full-3D layout. Returns that group or -1.
+template <class P>
+constexpr int star_group() {
+    int sg = -1;
+    for (int g = 0; g < P::n_groups; g++) {
+        StarRange r = analyze_group<P>(g);
+        if (!r.any) continue;
+        if (r.mixed) return -1;
+        bool off = r.xlo || r.xhi || r.ylo || r.yhi || r.zlo || r.zhi;
+        if (off) {
+            if (sg >= 0) return -1;
+            sg = g;
+        }
+    }
+    return sg;
+}
+
+template <class P>
+constexpr bool group_is_written(int g) {
+    for (int i = 0; i < P::n_writes; i++)
+        if (P::writes[i] == g) return true;
+    return false;
+}
+
+// ------------------------------------------------------------------ naive kernel
+template <class P>
+struct NaiveAcc {
+    typedef typename P::real_t T;
+    typedef T V;
+    const PartArgs& a;
+    int x, y, z;
+    template <int G, int DX, int DY, int DZ>
+    __device__ __forceinline__ V rd() const {
+        const T* p = (const T*)a.ptr[G];
+        return p[(idx_t)(x + DX) * a.gsx[G] + (idx_t)(y + DY) * a.gsy[G] + (idx_t)(z + DZ) * a.gsz[G]];
+    }
+    template <int G>
+    __device__ __forceinline__ void wr(V v) const {
+        T* p = (T*)a.ptr[G];
+        p[(idx_t)x * a.gsx[G] + (idx_t)y * a.gsy[G] + (idx_t)z * a.gsz[G]] = v;
+    }
+};
+
+template <class P>
+__global__ void __launch_bounds__(256) naive_kernel(const PartArgs a) {
+    int z = a.z0 + blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = a.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    int x = a.x0 + blockIdx.z;
+    if (z >= a.z1 || y >= a.y1 || x >= a.x1) return;
+    NaiveAcc<P> acc{a, x, y, z};
+    P::eval(acc);
+}
+
+// ------------------------------------------------------------------ star25d kernel
+enum { ROT_MOVE = 0, ROT_UNROLL = 1 };
+
+template <typename T, int S>
+__device__ __forceinline__ typename vtraits<T>::vec zshift(typename vtraits<T>::vec lo, typename vtraits<T>::vec hi) {
+    // elements S..S+VZ-1 of the concatenation (lo, hi)
+    if constexpr (vtraits<T>::VZ == 4) {
+        if constexpr (S == 0) return lo;
+        else if constexpr (S == 1) return __builtin_shufflevector(lo, hi, 1, 2, 3, 4);
+        else if constexpr (S == 2) return __builtin_shufflevector(lo, hi, 2, 3, 4, 5);
+        else return __builtin_shufflevector(lo, hi, 3, 4, 5, 6);
+    } else {
+        if constexpr (S == 0) return lo;
+        else return __builtin_shufflevector(lo, hi, 1, 2);
+    }
+}
+
+template <class P, int TZL_, int TYL_, int RY_, int ROT_>
+struct Star25dCfg {
+    typedef typename P::real_t T;
+    typedef vtraits<T> VT;
+    static constexpr int VZ = VT::VZ;
+    static constexpr int TZL = TZL_, TYL = TYL_, RY = RY_, ROT = ROT_;
+    static constexpr int NT = TZL * TYL;
+    static constexpr int SG = star_group<P>();
+    static constexpr StarRange R = analyze_group<P>(SG < 0 ? 0 : SG);
+    static constexpr int XL = -R.xlo, XH = R.xhi, YL = -R.ylo, YH = R.yhi, ZL = -R.zlo, ZH = R.zhi;
+    static constexpr int NQ = XL + XH + 1;
+    static constexpr int ZLV = (ZL + VZ - 1) / VZ, ZHV = (ZH + VZ - 1) / VZ;   // z halo in vectors
+    static constexpr int TZ = TZL * VZ, TY = TYL * RY;
+    static constexpr int LP = TZ + (ZLV + ZHV) * VZ;    // LDS row pitch (elements), multiple of VZ
+    static constexpr int LROWS = TY + YL + YH;
+    static constexpr int NHY = (YL + YH) * TZL;          // halo vectors above/below the tile
+    static constexpr int NHZ = TY * (ZLV + ZHV);         // halo vectors left/right of the tile
+    static constexpr int NH = NHY + NHZ;
+    static constexpr int NHT = (NH + NT - 1) / NT;       // halo vectors per thread
+    static constexpr int NW = ZLV + 1 + ZHV;             // z-window vectors per row
+    static constexpr int NYR = YL + RY + YH;             // y rows visible to a thread
+    static constexpr size_t lds_bytes = sizeof(T) * 2 * LROWS * LP;
+};
+
+template <class C, class P, int J>
+struct StarAcc {
+    typedef typename C::T T;
+    typedef typename C::VT::vec V;
+    static constexpr int VZ = C::VZ;
+    const PartArgs& a;
+    const V (&q)[C::NQ][C::RY];       // x queue, logical order (index XL = centre plane)
+    const V (&yr)[C::NYR];            // rows ly*RY-YL .. ly*RY+RY-1+YH at the thread's z
+    const V (&zw)[C::NW];             // z window of row j
+    const V (&cen)[MAX_GROUPS];       // centre-only operands of row j, by group
+    V (&out)[MAX_GROUPS];             // results of row j, by group
+    template <int G, int DX, int DY, int DZ>
+    __device__ __forceinline__ V rd() const {
+        if constexpr (G == C::SG) {
+            static_assert((DX != 0) + (DY != 0) + (DZ != 0) <= 1, "star25d: mixed offset");
+            if constexpr (DY == 0 && DZ == 0) return q[C::XL + DX][J];
+            else if constexpr (DZ == 0) return yr[C::YL + J + DY];
+            else {
+                constexpr int e = C::ZLV * VZ + DZ;      // first element within the window
+                return zshift<T, e % VZ>(zw[e / VZ], zw[(e / VZ + 1) < C::NW ? (e / VZ + 1) : e / VZ]);
+            }
+        } else {
+            static_assert(DX == 0 && DY == 0 && DZ == 0, "star25d: off-centre read of a non-star group");
+            return cen[G];
+        }
+    }
+    template <int G>
+    __device__ __forceinline__ void wr(V v) { out[G] = v; }
+};
+
+template <typename T>
+__device__ __forceinline__ typename vtraits<T>::vec ld_vec(const T* p) {
+    return *reinterpret_cast<const typename vtraits<T>::vec*>(p);
+}
+template <typename T>
+__device__ __forceinline__ void st_vec(T* p, typename vtraits<T>::vec v) {
+    *reinterpret_cast<typename vtraits<T>::vec*>(p) = v;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <class P, int TZL, int TYL, int RY, int ROT>
+__global__ void __launch_bounds__(TZL* TYL) star25d_kernel(const PartArgs a) {
+    typedef Star25dCfg<P, TZL, TYL, RY, ROT> C;
+    typedef typename C::T T;
+    typedef typename C::VT::vec V;
+    constexpr int VZ = C::VZ, NQ = C::NQ, XL = C::XL, XH = C::XH, YL = C::YL;
+    constexpr int ZLV = C::ZLV, ZHV = C::ZHV, LP = C::LP, NT = C::NT, NHT = C::NHT;
+    constexpr int SG = C::SG, NG = P::n_groups;
+    static_assert(SG >= 0, "part is not star-shaped");
+    static_assert(NG <= MAX_GROUPS, "too many access groups");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char ykh_smem[];
+    T* slab = reinterpret_cast<T*>(ykh_smem);
+
+    // ---- tile assignment, XCD-aware: consecutive block ids round-robin over the 8 XCDs
+    // (MI355X_MICROARCH.md "Workgroup dispatch"), so give each XCD a contiguous range of tiles:
+    // (y,z)-neighbour tiles then share one L2 and re-use each other's halo lines.
+    const int ntiles = a.ntz * a.nty * a.nxc;
+    int bid = blockIdx.x;
+    if ((ntiles & 7) == 0) bid = (bid & 7) * (ntiles >> 3) + (bid >> 3);
+    const int tz_i = bid % a.ntz;
+    const int ty_i = (bid / a.ntz) % a.nty;
+    const int xc_i = bid / (a.ntz * a.nty);
+
+    const int tid = threadIdx.x;
+    const int lz = tid % TZL, ly = tid / TZL;
+    // tile origin; z origin rounded down to a vector boundary (local index 0 is vector-aligned)
+    const int zt0 = (a.z0 & ~(VZ - 1)) + tz_i * C::TZ;
+    const int yt0 = a.y0 + ty_i * C::TY;
+    const int xs = a.x0 + xc_i * a.xchunk;
+    const int xe = (xs + a.xchunk < a.x1) ? xs + a.xchunk : a.x1;
+    if (xs >= xe) return;
+
+    const int myz = zt0 + lz * VZ;
+    const int zc = clampi(myz, a.az0, a.az1 - VZ);
+    const T* __restrict__ sp = (const T*)a.ptr[SG];
+
+    // per-row global offsets within a plane (clamped so that loads never leave the allocation)
+    idx_t roff[RY];
+    static_for<RY>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        int y = clampi(yt0 + ly * RY + j, a.ay0, a.ay1 - 1);
+        roff[j] = (idx_t)y * a.sy + zc;
+    });
+    // halo vectors owned by this thread: plane offset + LDS element offset
+    idx_t hoff[NHT];
+    int hlds[NHT];
+    static_for<NHT>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        int h = tid + k * NT;
+        int row, zv;   // LDS row, LDS vector column
+        if (h < C::NHY) {
+            int r = h / TZL;
+            row = r < YL ? r : r + C::TY;          // rows above, then rows below the tile
+            zv = ZLV + h % TZL;
+        } else {
+            int hh = h - C::NHY;
+            int r = hh / (ZLV + ZHV), c = hh % (ZLV + ZHV);
+            row = YL + r;
+            zv = c < ZLV ? c : c + TZL;            // left vectors, then right vectors
+        }
+        if (h >= C::NH) { row = 0; zv = 0; }
+        int y = clampi(yt0 - YL + row, a.ay0, a.ay1 - 1);
+        int z = clampi(zt0 - ZLV * VZ + zv * VZ, a.az0, a.az1 - VZ);
+        hoff[k] = (idx_t)y * a.sy + z;
+        hlds[k] = (h < C::NH) ? row * LP + zv * VZ : -1;
+    });
+
+    auto xplane = [&](int x) -> idx_t { return (idx_t)clampi(x, a.ax0, a.ax1 - 1) * a.sx; };
+
+    V q[NQ][RY];
+    V nxt[RY];
+    V hreg[NHT];
+    V cen_nxt[NG][RY];     // only entries of centre-read, non-star groups are ever touched
+
+    auto load_centres = [&](idx_t pc) {
+        static_for<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g != SG && analyze_group<P>(g).any) {
+                const T* gp = (const T*)a.ptr[g];
+                static_for<RY>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    cen_nxt[g][j] = ld_vec<T>(gp + pc + roff[j]);
+                });
+            }
+        });
+    };
+
+    // ---- prologue: fill the queue with planes xs-XL .. xs+XH-1, prefetch plane xs+XH,
+    // the halos of plane xs and the centre operands of plane xs.
+    static_for<NQ - 1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        idx_t po = xplane(xs - XL + i);
+        static_for<RY>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            q[i][j] = ld_vec<T>(sp + po + roff[j]);
+        });
+    });
+    {
+        idx_t po = xplane(xs + XH);
+        static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; nxt[j] = ld_vec<T>(sp + po + roff[j]); });
+        idx_t pc = xplane(xs);
+        static_for<NHT>([&](auto kc) { constexpr int k = decltype(kc)::value; hreg[k] = ld_vec<T>(sp + pc + hoff[k]); });
+        load_centres(pc);
+    }
+
+    // One plane of work. `PH` rotates the physical queue so that no register moves are needed
+    // when the x loop is unrolled NQ times (ROT_UNROLL); with ROT_MOVE, PH is always 0.
+    auto plane = [&](int x, auto ph_tag) {
+        constexpr int PH = decltype(ph_tag)::value;
+        T* sb = slab + (x & 1) * (C::LROWS * LP);
+        // newest plane completes the queue
+        static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; q[(PH + NQ - 1) % NQ][j] = nxt[j]; });
+        // stage the centre plane: interior from registers, halos from the prefetched registers
+        static_for<RY>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            st_vec<T>(sb + (YL + ly * RY + j) * LP + (ZLV + lz) * VZ, q[(PH + XL) % NQ][j]);
+        });
+        static_for<NHT>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (hlds[k] >= 0) st_vec<T>(sb + hlds[k], hreg[k]);
+        });
+        // centre operands of this plane were prefetched last iteration
+        V cen[NG][RY];
+        static_for<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g != SG && analyze_group<P>(g).any)
+                static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; cen[g][j] = cen_nxt[g][j]; });
+        });
+        // prefetch for the next plane before the barrier (overlaps with this plane's math)
+        if (x + 1 < xe) {
+            idx_t po = xplane(x + 1 + XH), pc = xplane(x + 1);
+            static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; nxt[j] = ld_vec<T>(sp + po + roff[j]); });
+            static_for<NHT>([&](auto kc) { constexpr int k = decltype(kc)::value; hreg[k] = ld_vec<T>(sp + pc + hoff[k]); });
+            load_centres(pc);
+        }
+        __syncthreads();
+
+        // logical view of the queue for the accessor
+        V ql[NQ][RY];
+        static_for<NQ>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; ql[i][j] = q[(PH + i) % NQ][j]; });
+        });
+        // rows visible to this thread along y (own rows come from registers)
+        V yr[C::NYR];
+        const T* colp = sb + (ZLV + lz) * VZ;
+        static_for<C::NYR>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            if constexpr (r >= YL && r < YL + RY) yr[r] = ql[XL][r - YL];
+            else yr[r] = ld_vec<T>(colp + (ly * RY + r) * LP);
+        });
+        const idx_t pc = (idx_t)x * a.sx;
+        static_for<RY>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            V zw[C::NW];
+            const T* rowp = sb + (YL + ly * RY + j) * LP + lz * VZ;
+            static_for<C::NW>([&](auto wc) {
+                constexpr int w = decltype(wc)::value;
+                if constexpr (w == ZLV) zw[w] = ql[XL][j];
+                else zw[w] = ld_vec<T>(rowp + w * VZ);
+            });
+            V cj[MAX_GROUPS], out[MAX_GROUPS];
+            static_for<NG>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if constexpr (g != SG && analyze_group<P>(g).any) cj[g] = cen[g][j];
+            });
+            StarAcc<C, P, j> acc{a, ql, yr, zw, cj, out};
+            P::eval(acc);
+            // predicated stores (tile may overhang the compute box)
+            const int y = yt0 + ly * RY + j;
+            if (y < a.y1 && myz < a.z1 && myz + VZ > a.z0) {
+                const idx_t o = pc + (idx_t)y * a.sy + myz;
+                static_for<P::n_writes>([&](auto wc) {
+                    constexpr int g = P::writes[decltype(wc)::value];
+                    T* op = (T*)a.ptr[g] + o;
+                    if (myz >= a.z0 && myz + VZ <= a.z1) st_vec<T>(op, out[g]);
+                    else
+                        static_for<VZ>([&](auto ec) {
+                            constexpr int e = decltype(ec)::value;
+                            if (myz + e >= a.z0 && myz + e < a.z1) op[e] = out[g][e];
+                        });
+                });
+            }
+        });
+    };
+
+    if constexpr (ROT == ROT_MOVE) {
+        for (int x = xs; x < xe; x++) {
+            plane(x, std::integral_constant<int, 0>{});
+            static_for<NQ - 1>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; q[i][j] = q[i + 1][j]; });
+            });
+        }
+    } else {
+        // NQ planes per trip; the physical queue slot of logical entry i is (PH+i)%NQ, so the
+        // queue rotates by renaming instead of by register moves.
+        int x = xs;
+        while (x < xe) {
+            bool go = true;
+            static_for<NQ>([&](auto phc) {
+                if (go) {
+                    if (x < xe) { plane(x, phc); x++; }
+                    else go = false;
+                }
+            });
+        }
+    }
+}
+
+}  // namespace ykh

@@ -1,0 +1,178 @@
+// ykh_halo.cpp -- per-GPU domain decomposition: halo pack -> transport -> unpack.
+//
+// GPU re-design of StencilContext::exchange_halos (src/kernel/lib/halo.cpp:80-491) and of the
+// buffer geometry computed by alloc_mpi_data (src/kernel/lib/alloc.cpp:456-859):
+//   * neighbours: up to 3^N-1, pruned per var by its L1 norm (faces only when l1_norm == 1);
+//   * what is sent to the neighbour at offset o: in each dim d with o[d] = -1 my first halo_r[d]
+//     domain points (they fill the neighbour's right halo), with o[d] = +1 my last halo_l[d] points,
+//     with o[d] = 0 my whole extent in d -- extended into my own halo at a *global* boundary when the
+//     var is read diagonally (l1_norm > 1), as alloc.cpp:544-553 does, so that corner cells end up
+//     identical to a single-rank run;
+//   * only (var, step-slot) pairs marked dirty are exchanged (src/kernel/lib/yk_var.cpp:122-152);
+//   * unlike the reference (one MPI message per var per neighbour, tag = var ordinal) all dirty slabs
+//     for one neighbour travel in ONE message: xGMI is point-to-point, so fewer/larger transfers win;
+//   * pack and unpack are box-copy kernels on the communication stream; the transport is stream
+//     ordered (RCCL ncclSend/ncclRecv inside one group, or a host callback), so run() can overlap the
+//     whole exchange with the interior kernel on the compute stream.
+#include <algorithm>
+#include <cstring>
+
+#include "ykh_runtime.hpp"
+
+namespace ykh {
+
+static bool slab_for(const Solution& s, const Var& v, const Solution::Neighbor& nb, bool sending, Slab& out) {
+    if (v.fixed_size || v.l1_norm < nb.l1 || !v.is_allocated()) return false;
+    out.elems = 1;
+    for (int d = 0; d < MAX_DOMAIN_DIMS; d++) {
+        const int o = nb.ofs[d];
+        if (d >= s.ndd || !v.uses_domain[d]) {
+            if (o != 0) return false;   // var does not extend in a dim the neighbour is offset in
+            out.lo[d] = 0; out.n[d] = 1;
+            continue;
+        }
+        const idx_t n = v.dom_size[d];
+        if (o == 0) {
+            idx_t lo = 0, hi = n;
+            if (v.l1_norm > 1) {
+                if (s.rank_index[d] == 0) lo -= v.halo_l[d];
+                if (s.rank_index[d] == s.num_ranks[d] - 1) hi += v.halo_r[d];
+            }
+            out.lo[d] = lo; out.n[d] = hi - lo;
+        } else if (sending) {
+            // to the left neighbour: my first halo_r points; to the right: my last halo_l points
+            idx_t w = (o < 0) ? v.halo_r[d] : v.halo_l[d];
+            out.lo[d] = (o < 0) ? 0 : n - w;
+            out.n[d] = w;
+        } else {
+            // from the left neighbour into my left halo; from the right into my right halo
+            idx_t w = (o < 0) ? v.halo_l[d] : v.halo_r[d];
+            out.lo[d] = (o < 0) ? -w : n;
+            out.n[d] = w;
+        }
+        if (out.n[d] <= 0) return false;
+        out.elems *= out.n[d];
+    }
+    out.elems *= v.misc_elems;
+    return true;
+}
+
+void Solution::alloc_halo_buffers() {
+    if (env->nranks <= 1) return;
+    for (auto& nb : neighbors) {
+        auto x = std::make_unique<NeighborXfer>();
+        x->nb = nb;
+        size_t sb = 0, rb = 0;
+        for (size_t i = 0; i < vars.size(); i++) {
+            Slab sl;
+            sl.var = (int)i;
+            if (slab_for(*this, *vars[i], nb, true, sl)) { x->send.push_back(sl); sb += (size_t)sl.elems * vars[i]->nslots; }
+            if (slab_for(*this, *vars[i], nb, false, sl)) { x->recv.push_back(sl); rb += (size_t)sl.elems * vars[i]->nslots; }
+        }
+        x->send_cap = sb * elem_bytes();
+        x->recv_cap = rb * elem_bytes();
+        if (x->send_cap) YKH_HIP(hipMalloc(&x->send_buf, x->send_cap));
+        if (x->recv_cap) YKH_HIP(hipMalloc(&x->recv_buf, x->recv_cap));
+        if (x->send_cap || x->recv_cap) xfers.push_back(std::move(x));
+    }
+}
+
+void Solution::free_halo_buffers() {
+    for (auto& x : xfers) {
+        if (x->send_buf) (void)hipFree(x->send_buf);
+        if (x->recv_buf) (void)hipFree(x->recv_buf);
+    }
+    xfers.clear();
+}
+
+// Copy every dirty (var, slot) slab of `slabs` between the vars and the contiguous buffer.
+static size_t move_slabs(Solution& s, const std::vector<Slab>& slabs, void* buf, bool pack, hipStream_t st) {
+    size_t ofs = 0;
+    const int eb = s.elem_bytes();
+    for (const Slab& sl : slabs) {
+        Var& v = *s.vars[sl.var];
+        for (int slot = 0; slot < v.nslots; slot++) {
+            if (!v.dirty[slot]) continue;
+            // misc indices are laid out outside the domain dims: copy each misc plane
+            std::vector<idx_t> mofs = {0};
+            for (size_t p = 0; p < v.dims.size(); p++) {
+                if (v.dims[p].type != DIM_MISC) continue;
+                std::vector<idx_t> nxt;
+                for (idx_t m = 0; m <= v.dims[p].last_misc - v.dims[p].first_misc; m++)
+                    for (idx_t b : mofs) nxt.push_back(b + m * v.misc_stride[p]);
+                mofs.swap(nxt);
+            }
+            for (idx_t mo : mofs) {
+                BoxCopyArgs a{};
+                a.var_elem_bytes = a.buf_elem_bytes = eb;
+                a.var_base = (char*)v.dptr + ((size_t)slot * v.slot_elems + v.origin_elems + mo) * eb;
+                a.sx = v.stride[0]; a.sy = v.stride[1]; a.sz = v.stride[2];
+                for (int d = 0; d < 3; d++) { a.lo[d] = sl.lo[d]; a.n[d] = sl.n[d]; }
+                a.bs[2] = 1; a.bs[1] = sl.n[2]; a.bs[0] = sl.n[1] * sl.n[2];
+                a.buf = (char*)buf + ofs;
+                if (pack) launch_box_gather(a, st);
+                else launch_box_scatter(a, st);
+                ofs += (size_t)(sl.n[0] * sl.n[1] * sl.n[2]) * eb;
+            }
+        }
+    }
+    return ofs;
+}
+
+// start_only : pack + begin transport on the comm stream (after everything queued on the compute stream);
+// finish_only: wait for arrival, unpack, and make the compute stream wait for the unpack.
+void Solution::exchange_halos(idx_t /*t_written*/, int /*stage*/, bool start_only, bool finish_only) {
+    if (env->nranks <= 1 || xfers.empty()) return;
+    if (!env->exch_start) YKH_THROW("multi-rank solution has no halo-exchange transport installed in its env");
+    static thread_local std::vector<HaloMsg> msgs;
+    if (!finish_only) {
+        bool any = false;
+        for (auto& v : vars)
+            for (char d : v->dirty) any |= (d != 0);
+        msgs.clear();
+        if (!any) return;
+        // comm stream waits for the kernels that produced the data
+        YKH_HIP(hipEventRecord(ev_a, compute_stream));
+        YKH_HIP(hipStreamWaitEvent(comm_stream, ev_a, 0));
+        for (auto& x : xfers) {
+            x->send_now = move_slabs(*this, x->send, x->send_buf, true, comm_stream);
+            // receive size: same rule evaluated on my recv slabs (neighbour's dirty flags mirror mine)
+            size_t r = 0;
+            for (const Slab& sl : x->recv) {
+                Var& v = *vars[sl.var];
+                for (int slot = 0; slot < v.nslots; slot++)
+                    if (v.dirty[slot]) r += (size_t)sl.elems * elem_bytes();
+            }
+            x->recv_now = r;
+            if (!x->send_now && !x->recv_now) continue;
+            HaloMsg m;
+            m.peer = x->nb.rank;
+            m.send_buf = x->send_buf; m.recv_buf = x->recv_buf;
+            m.send_bytes = x->send_now; m.recv_bytes = x->recv_now;
+            // tag encodes the direction so that both messages between a pair of ranks are distinct
+            m.tag = (x->nb.ofs[0] + 1) * 9 + (x->nb.ofs[1] + 1) * 3 + (x->nb.ofs[2] + 1);
+            msgs.push_back(m);
+        }
+        if (!msgs.empty() && env->exch_start(env->user, (int)msgs.size(), msgs.data(), (void*)comm_stream) != 0)
+            YKH_THROW("halo-exchange transport failed to start");
+    }
+    if (!start_only) {
+        if (msgs.empty()) return;
+        if (env->exch_wait && env->exch_wait(env->user, (int)msgs.size(), msgs.data(), (void*)comm_stream) != 0)
+            YKH_THROW("halo-exchange transport failed while waiting");
+        for (auto& x : xfers)
+            if (x->recv_now) move_slabs(*this, x->recv, x->recv_buf, false, comm_stream);
+        YKH_HIP(hipEventRecord(ev_b, comm_stream));
+        YKH_HIP(hipStreamWaitEvent(compute_stream, ev_b, 0));
+        for (auto& v : vars) v->set_dirty_all(false);
+        msgs.clear();
+    }
+}
+
+void Solution::exchange_halos_all() {
+    if (!prepared) YKH_THROW("exchange_halos() called without calling prepare_solution() first");
+    exchange_halos(0, 0, true, false);
+    exchange_halos(0, 0, false, true);
+}
+
+}  // namespace ykh

@@ -1,0 +1,87 @@
+// ykh_meta.hpp -- compile-time description of a stencil solution, as emitted by the
+// `cdna4_hip` compiler target (yask_amd/compiler/YaskHipPrinter.cpp) and consumed by the HIP
+// runtime. It carries the same facts the reference bakes into its generated context
+// (src/compiler/lib/YaskKernel.cpp:730-1181 `print_context`): dims, vars, per-var halos,
+// step-slot counts, L1 norms, parts, stages and their dependencies.
+#pragma once
+
+namespace ykh {
+
+using idx_t = long long;
+
+constexpr int MAX_DOMAIN_DIMS = 3;   // this runtime is specialised for <=3 spatial dims
+constexpr int MAX_VAR_DIMS = 6;
+
+enum DimType { DIM_STEP = 0, DIM_DOMAIN = 1, DIM_MISC = 2 };
+
+struct DimMeta {
+    const char* name;
+    int type;        // DimType
+    int domain_idx;  // 0..ndomain-1 for domain dims (0 = outermost = largest stride), else -1
+};
+
+struct VarMeta {
+    const char* name;
+    int ndims;
+    int dims[MAX_VAR_DIMS];           // indices into SolnMeta::dims, in declaration order
+    int step_alloc;                   // number of step slots (0 if var has no step dim)
+    int halo_l[MAX_DOMAIN_DIMS];      // by domain_idx
+    int halo_r[MAX_DOMAIN_DIMS];
+    int misc_first[MAX_VAR_DIMS];     // by position in dims[] (only misc dims meaningful)
+    int misc_last[MAX_VAR_DIMS];
+    int l1_norm;                      // max L1 distance of any read (prunes halo-exchange neighbours)
+    bool is_scratch;
+    bool is_written;                  // updated by some equation
+};
+
+// One distinct (var, step offset) pair touched by a part: kernels receive one base pointer each.
+struct AccessGroup {
+    int var;        // index into SolnMeta::vars
+    int dt;         // step offset relative to the evaluation step t (0 if var has no step dim)
+    bool has_step;
+};
+
+struct ReadOff {
+    signed char g;            // access-group index
+    signed char dx, dy, dz;   // offsets by domain_idx (x = domain_idx 0)
+};
+
+struct PartMeta {
+    const char* name;
+    int n_groups;
+    const AccessGroup* groups;
+    int n_reads;
+    const ReadOff* reads;
+    int n_writes;
+    const int* writes;        // group indices written
+    int fp_ops;               // per-point stats, as the reference reports them
+    int points_read;
+    int points_written;
+    int stage;                // owning stage
+    bool has_domain_cond;
+    bool has_step_cond;
+};
+
+struct StageMeta {
+    const char* name;
+    int n_parts;
+    const int* parts;
+};
+
+struct SolnMeta {
+    const char* name;
+    const char* description;
+    const char* target;        // "cdna4_hip"
+    int elem_bytes;
+    int ndims;
+    const DimMeta* dims;       // step dim first, then domain dims (outer->inner), then misc dims
+    int step_dir;              // +1 forward, -1 reverse
+    int n_vars;
+    const VarMeta* vars;
+    int n_parts;
+    const PartMeta* parts;
+    int n_stages;
+    const StageMeta* stages;
+};
+
+}  // namespace ykh

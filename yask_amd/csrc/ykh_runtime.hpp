@@ -1,0 +1,351 @@
+// ykh_runtime.hpp -- host side of the MI355X stencil runtime ("ykh" = YASK kernel, HIP).
+//
+// Mirrors, for the GPU, the pieces of the reference's StencilContext that sit on the
+// run_solution() hot path:
+//   Var       <- YkVarBase/YkVarImpl + GenericVar   (src/kernel/lib/yk_var.{hpp,cpp}, generic_var.*)
+//   Solution  <- StencilContext + KernelSettings     (src/kernel/lib/context.*, settings.*, setup.cpp,
+//                                                      soln_apis.cpp, alloc.cpp, halo.cpp, auto_tuner.*)
+//   Env       <- KernelEnv                           (src/kernel/lib/settings.hpp:60-140, setup.cpp:38-137)
+// Storage is device-resident, plain row-major [step][misc..][x][y][z] with z unit-stride (no vector
+// folding: the 64 lanes of a wavefront span z).  The public faces are the C ABI in
+// include/yask_hip_c_api.h and, on top of it, the C++ yk_* classes (yask_amd/cxxapi) and the Python
+// package yask_amd.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ykh_device.hpp"
+#include "ykh_meta.hpp"
+
+namespace ykh {
+
+// Same message prefix as yask::yask_exception (include/yask_common_api.hpp:125-179).
+struct Error : public std::runtime_error {
+    explicit Error(const std::string& m) : std::runtime_error("YASK error: " + m) {}
+};
+#define YKH_THROW(msg) throw ::ykh::Error(std::string(msg))
+#define YKH_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            throw ::ykh::Error(std::string(#call) + " failed: " + hipGetErrorString(e_));          \
+    } while (0)
+
+// ------------------------------------------------------------------ kernel registry (per stencil lib)
+struct KernelVariant {
+    const char* name;      // e.g. "star25d_z32_y8_r1_u"
+    bool star;             // false: naive
+    int tz, ty;            // tile extent in elements (star only)
+    size_t lds_bytes;
+    int threads;
+    void (*launch)(const PartArgs& a, dim3 grid, hipStream_t s);
+};
+struct PartImpl {
+    const PartMeta* meta;
+    std::vector<KernelVariant> variants;   // variants[0] is the always-legal naive kernel
+    int default_variant;
+};
+struct SolnImpl {
+    const SolnMeta* meta;
+    std::vector<PartImpl> parts;
+};
+// Defined once per stencil library (stencil_<name>.hip).
+const SolnImpl& ykh_solution_impl();
+
+// ------------------------------------------------------------------ Env
+// Halo-exchange transport. The runtime packs every outgoing halo into a contiguous device buffer and
+// hands the transport a list of (peer, send buffer, recv buffer, bytes, tag) messages; the transport
+// moves the bytes (RCCL send/recv over xGMI, or a host-provided callback -- e.g. torch.distributed).
+struct HaloMsg {
+    int peer;           // neighbour rank
+    void* send_buf;     // device pointer (contiguous), may be null if nbytes_send == 0
+    void* recv_buf;     // device pointer (contiguous)
+    size_t send_bytes;
+    size_t recv_bytes;
+    int tag;
+};
+typedef int (*ykh_exchange_fn)(void* user, int nmsgs, const HaloMsg* msgs, void* stream);
+typedef int (*ykh_allreduce_fn)(void* user, int op /*0 sum,1 min,2 max*/, long long* val);
+
+class Env {
+public:
+    int rank = 0, nranks = 1;
+    int device = 0;
+    ykh_exchange_fn exch_start = nullptr;   // begin moving all msgs (async on `stream`)
+    ykh_exchange_fn exch_wait = nullptr;    // make `stream` wait until they have landed
+    ykh_allreduce_fn allreduce = nullptr;
+    void* user = nullptr;
+    bool trace = false;
+    Env();
+    void set_ranks(int rank_, int nranks_);
+    long long sum_over_ranks(long long v) const;
+    long long min_over_ranks(long long v) const;
+    long long max_over_ranks(long long v) const;
+};
+
+// ------------------------------------------------------------------ Var
+class Solution;
+
+struct VarDim {
+    std::string name;
+    int type;          // DimType
+    int domain_idx;    // for domain dims
+    idx_t first_misc = 0, last_misc = 0;   // misc dims
+};
+
+class Var {
+public:
+    Var(Solution* soln, const VarMeta* meta, int ordinal);
+    Var(Solution* soln, const std::string& name, const std::vector<std::string>& dims, int ordinal,
+        const std::vector<idx_t>* fixed_sizes);
+    ~Var();
+
+    Solution* soln;
+    const VarMeta* meta;       // null for user-created vars
+    std::string name;
+    int ordinal;
+    std::vector<VarDim> dims;
+    bool fixed_size = false;
+    std::vector<idx_t> fixed_sizes;     // by dim position (fixed-size vars)
+    bool has_step = false;
+    int step_posn = -1;
+    int nslots = 1;
+    bool dynamic_step_alloc = false;
+    int l1_norm = 0;
+    bool is_written = false;
+
+    // per domain_idx geometry (valid after Solution::prepare or set for fixed-size vars)
+    bool uses_domain[MAX_DOMAIN_DIMS] = {false, false, false};
+    idx_t dom_size[MAX_DOMAIN_DIMS] = {1, 1, 1};      // rank-domain size in this dim
+    idx_t rank_ofs[MAX_DOMAIN_DIMS] = {0, 0, 0};      // global index of local 0
+    idx_t halo_l[MAX_DOMAIN_DIMS] = {0, 0, 0}, halo_r[MAX_DOMAIN_DIMS] = {0, 0, 0};
+    idx_t min_pad_l[MAX_DOMAIN_DIMS] = {0, 0, 0}, min_pad_r[MAX_DOMAIN_DIMS] = {0, 0, 0};
+    idx_t pad_l[MAX_DOMAIN_DIMS] = {0, 0, 0}, pad_r[MAX_DOMAIN_DIMS] = {0, 0, 0};
+    idx_t stride[MAX_DOMAIN_DIMS] = {0, 0, 0};        // element stride (0 if dim unused)
+    idx_t misc_elems = 1;                              // product of misc-dim sizes
+    std::vector<idx_t> misc_stride;                    // by dim position
+    idx_t slot_elems = 0;                              // elements per step slot
+    idx_t first_valid_step = 0;
+
+    int elem_bytes() const;
+    bool is_allocated() const { return dptr != nullptr; }
+    void compute_geometry();          // sizes/strides from soln settings (no allocation)
+    void allocate();                  // hipMalloc + zero
+    void release();
+    size_t bytes() const { return (size_t)slot_elems * nslots * elem_bytes(); }
+
+    // device address of local element (0,..,0) of the slot holding step t
+    void* slot_base(idx_t t) const;
+    int slot_of(idx_t t) const;
+    idx_t last_valid_step() const { return first_valid_step + nslots - 1; }
+    void update_valid_step(idx_t t);
+
+    // index helpers (by dim position, global indices as in the reference API)
+    idx_t first_local_index(int posn) const;
+    idx_t last_local_index(int posn) const;
+    idx_t alloc_size(int posn) const;
+    int dim_posn(const std::string& dim, bool must_exist = true) const;
+    bool indices_local(const std::vector<idx_t>& idx) const;
+    std::string format_indices(const std::vector<idx_t>& idx) const;
+    void check_indices(const std::vector<idx_t>& idx, const char* fn, bool strict, bool check_step,
+                       bool* clipped = nullptr) const;
+
+    // element / slice access (global indices, inclusive bounds)
+    double get_element(const std::vector<idx_t>& idx) const;
+    idx_t set_element(double v, const std::vector<idx_t>& idx, bool strict);
+    idx_t add_to_element(double v, const std::vector<idx_t>& idx, bool strict);
+    idx_t get_elements_in_slice(void* buf, size_t buf_elems, int buf_elem_bytes,
+                                const std::vector<idx_t>& first, const std::vector<idx_t>& last) const;
+    idx_t set_elements_in_slice(const void* buf, size_t buf_elems, int buf_elem_bytes,
+                                const std::vector<idx_t>& first, const std::vector<idx_t>& last);
+    idx_t set_elements_in_slice_same(double v, const std::vector<idx_t>& first,
+                                     const std::vector<idx_t>& last, bool strict);
+    void set_all_elements_same(double v);
+    // extension: logical-index hash init (offset + scale*H(ordinal, slot, gx, gy, gz)) over
+    // domain+halo of every slot; same function as oracle/stencil_oracle.c:yo_hash_unit.
+    void set_elements_hash(double offset, double scale, int hash_id);
+    struct Reduction { idx_t n = 0; double sum = 0, sum_sq = 0, prod = 1, vmax = 0, vmin = 0; int mask = 0; };
+    Reduction reduce_elements_in_slice(int mask, const std::vector<idx_t>& first,
+                                       const std::vector<idx_t>& last, bool strict) const;
+    // count of mismatching in-domain elements vs another var (compare_data, yk_var.cpp:401-477)
+    idx_t compare(const Var& ref, double epsilon) const;
+
+    // dirty flags per slot (halo needs exchange), src/kernel/lib/yk_var.cpp:122-152
+    std::vector<char> dirty;
+    void set_dirty(bool d, idx_t t);
+    void set_dirty_all(bool d);
+    bool is_dirty(idx_t t) const;
+
+    // host mirror for get_raw_storage_buffer()
+    void* host_mirror();
+    void sync_mirror_to_device();
+    void* dptr = nullptr;        // device allocation base
+    idx_t origin_elems = 0;      // element offset of local (0,0,0), misc first, within a slot
+private:
+    void init_dims_from_meta();
+    std::vector<char> mirror_;
+    bool mirror_valid_ = false;
+    // iterate the (slot, misc) combinations of a slice and call fn(slot_base_ptr_at_misc, buffer offset)
+    template <class F> idx_t for_boxes(const std::vector<idx_t>& first, const std::vector<idx_t>& last,
+                                       bool strict, bool update_step, F&& fn) const;
+};
+
+// ------------------------------------------------------------------ Stats (yk_stats)
+struct Stats {
+    idx_t num_elements = 0;
+    idx_t num_steps_done = 0;
+    idx_t num_writes_done = 0;
+    idx_t est_fp_ops_done = 0;
+    idx_t num_reads_done = 0;
+    double elapsed_secs = 0.0;
+    double halo_secs = 0.0;
+    double pts_per_sec = 0.0;
+};
+
+// ------------------------------------------------------------------ Solution
+struct Box { idx_t lo[MAX_DOMAIN_DIMS], hi[MAX_DOMAIN_DIMS]; bool empty() const; };
+
+struct NeighborXfer;   // halo buffers per neighbour (below)
+
+class Solution {
+public:
+    Solution(std::shared_ptr<Env> env, const SolnImpl& impl);
+    ~Solution();
+
+    std::shared_ptr<Env> env;
+    const SolnImpl& impl;
+    const SolnMeta* meta;
+    int ndd;                                   // number of domain dims
+    std::vector<std::string> domain_dim_names;
+    std::string step_dim_name;
+    std::vector<std::string> misc_dim_names;
+
+    // ---- settings (KernelSettings, src/kernel/lib/settings.hpp:140-330)
+    idx_t global_size[MAX_DOMAIN_DIMS] = {0, 0, 0};
+    idx_t rank_size[MAX_DOMAIN_DIMS] = {0, 0, 0};     // requested (0 = derive)
+    idx_t num_ranks[MAX_DOMAIN_DIMS] = {0, 0, 0};
+    idx_t rank_index[MAX_DOMAIN_DIMS] = {0, 0, 0};
+    bool rank_index_set = false;
+    idx_t block_size[MAX_DOMAIN_DIMS + 1] = {0, 0, 0, 0};   // [0]=step, then domain dims; accepted, advisory
+    idx_t min_pad[MAX_DOMAIN_DIMS] = {0, 0, 0};
+    idx_t extra_pad[MAX_DOMAIN_DIMS] = {0, 0, 0};
+    bool overlap_comms = true;
+    idx_t min_exterior = 0;
+    bool do_halo_exchange = true;
+    bool auto_tune = false;        // tuned at prepare() when true
+    double auto_tune_trial_secs = 0.05;
+    bool force_scalar = false;     // use the naive kernel everywhere
+    std::string variant_override;  // -hip_variant <name>
+    idx_t xchunk_override = 0;     // -hip_xchunk <n>
+    std::map<std::string, std::string> ignored_opts;   // accepted reference options with no GPU meaning
+    std::string apply_command_line_options(const std::vector<std::string>& args);
+    std::string get_command_line_help() const;
+    std::string get_command_line_values() const;
+
+    // ---- state
+    bool prepared = false;
+    idx_t rank_ofs[MAX_DOMAIN_DIMS] = {0, 0, 0};
+    idx_t local_size[MAX_DOMAIN_DIMS] = {0, 0, 0};   // computed rank-domain size
+    std::vector<std::shared_ptr<Var>> vars;
+    std::map<std::string, std::shared_ptr<Var>> var_map;
+    std::vector<int> part_variant;                   // chosen variant per part
+    std::vector<idx_t> part_xchunk;
+    hipStream_t compute_stream = nullptr, comm_stream = nullptr;
+    bool own_streams = false;
+    Stats stats;
+    idx_t steps_done_total = 0;
+
+    // neighbours (MPIInfo, src/kernel/lib/settings.hpp:331-433)
+    struct Neighbor { int rank; int ofs[MAX_DOMAIN_DIMS]; int l1; };
+    std::vector<Neighbor> neighbors;
+
+    // hooks (soln_apis.cpp:116-133)
+    typedef std::function<void(Solution&)> hook_fn;
+    typedef std::function<void(Solution&, idx_t, idx_t)> hook_t_fn;
+    std::vector<hook_fn> before_prepare, after_prepare;
+    std::vector<hook_t_fn> before_run, after_run;
+
+    // ---- API
+    void set_streams(hipStream_t compute, hipStream_t comm);
+    std::shared_ptr<Var> get_var(const std::string& name) const;
+    std::shared_ptr<Var> new_var(const std::string& name, const std::vector<std::string>& dims);
+    std::shared_ptr<Var> new_fixed_size_var(const std::string& name, const std::vector<std::string>& dims,
+                                            const std::vector<idx_t>& sizes);
+    int domain_dim_idx(const std::string& dim, const char* fn) const;
+    void invalidate() { prepared = false; }
+    void prepare();
+    void end();
+    void run(idx_t first_step, idx_t last_step);
+    void exchange_halos_all();
+    Stats get_stats();       // returns and clears, like soln_apis.cpp:349-562
+    void reset_auto_tuner(bool enable);
+    void run_auto_tuner_now();
+    idx_t compare_data(const Solution& ref, double epsilon) const;
+    void copy_vars_to_device() {}
+    void copy_vars_from_device() {}
+    void synchronize();
+
+    // internals used by ykh_halo.cpp / tuner
+    void setup_rank();
+    void launch_part(int part, idx_t t, const Box& box, hipStream_t s);
+    void launch_part_variant(int part, int variant, idx_t xchunk, idx_t t, const Box& box, hipStream_t s);
+    void fill_part_args(int part, idx_t t, const Box& box, PartArgs& a) const;
+    void alloc_halo_buffers();
+    void free_halo_buffers();
+    void exchange_halos(idx_t t_written, int stage, bool start_only, bool finish_only);
+    Box rank_box() const;
+    Box interior_box;                 // rank box shrunk where a neighbour exists (overlap_comms)
+    bool have_interior = false;
+    std::vector<std::unique_ptr<NeighborXfer>> xfers;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    int elem_bytes() const { return meta->elem_bytes; }
+    idx_t shared_pad_l(int d) const { return shared_pad_l_[d]; }
+    idx_t shared_pad_r(int d) const { return shared_pad_r_[d]; }
+    idx_t shared_pad_l_[MAX_DOMAIN_DIMS] = {0, 0, 0}, shared_pad_r_[MAX_DOMAIN_DIMS] = {0, 0, 0};
+};
+
+// one var's region for one neighbour, and the per-neighbour buffers (see ykh_halo.cpp)
+struct Slab {
+    int var;            // index into Solution::vars
+    idx_t lo[3], n[3];  // local box
+    idx_t elems;        // per step slot (all misc indices)
+};
+struct NeighborXfer {
+    Solution::Neighbor nb;
+    std::vector<Slab> send, recv;
+    void* send_buf = nullptr;
+    void* recv_buf = nullptr;
+    size_t send_cap = 0, recv_cap = 0;   // bytes
+    size_t send_now = 0, recv_now = 0;   // bytes in the current exchange
+};
+
+std::string version_string();
+
+// utility kernels (ykh_util_kernels.hip)
+struct BoxCopyArgs {
+    void* var_base;       // address of local element (0,0,0) of the slot (+misc offset)
+    void* buf;            // contiguous buffer
+    idx_t sx, sy, sz;     // var strides
+    idx_t lo[3], n[3];    // box origin (local) and extent
+    idx_t bs[3];          // buffer strides (elements) for box dims x,y,z
+    int var_elem_bytes, buf_elem_bytes;
+};
+void launch_box_gather(const BoxCopyArgs& a, hipStream_t s);    // var -> buf
+void launch_box_scatter(const BoxCopyArgs& a, hipStream_t s);   // buf -> var
+void launch_box_fill(const BoxCopyArgs& a, double v, hipStream_t s);
+void launch_box_add(const BoxCopyArgs& a, double v, hipStream_t s);
+void launch_box_hash(const BoxCopyArgs& a, double offset, double scale, idx_t vid, idx_t slot,
+                     idx_t gx, idx_t gy, idx_t gz, hipStream_t s);
+// reduce over a box: out[0]=sum out[1]=sumsq out[2]=prod out[3]=max out[4]=min (doubles, device memory)
+void launch_box_reduce(const BoxCopyArgs& a, double* out5, hipStream_t s);
+// count elements of box a differing from box b (same extents) beyond epsilon (reference rule)
+void launch_box_compare(const BoxCopyArgs& a, const BoxCopyArgs& b, double eps, unsigned long long* count,
+                        hipStream_t s);
+
+}  // namespace ykh

@@ -1,0 +1,715 @@
+// ykh_solution.cpp -- the HIP launch-grid scheduler behind yk_solution.
+//
+// GPU re-design of the reference's L3 runtime on the run_solution() path:
+//   StencilContext::run_solution / calc_mega_block / calc_block / calc_micro_block
+//       (src/kernel/lib/context.cpp:220-1174)        -> Solution::run(): per step, per stage, per part
+//       one kernel launch over the rank box (or exterior slabs + interior when halos are exchanged);
+//   prepare_solution chain (src/kernel/lib/soln_apis.cpp:137-249; setup.cpp:169-524,666-805;
+//       alloc.cpp:343-452)                            -> Solution::prepare(): rank grid, sizes, device allocation;
+//   exchange_halos (src/kernel/lib/halo.cpp:80-491), buffer geometry alloc_mpi_data
+//       (src/kernel/lib/alloc.cpp:456-859)            -> pack kernel -> transport (RCCL) -> unpack kernel on a
+//       side stream, overlapped with the interior launch (exterior-first order of context.cpp:377-478);
+//   get_stats (src/kernel/lib/soln_apis.cpp:349-562)  -> Solution::get_stats();
+//   AutoTuner (src/kernel/lib/auto_tuner.cpp:206-586) -> run_auto_tuner_now(): times the compiled tile shapes;
+//   KernelSettings::add_options (src/kernel/lib/settings.cpp:328-524) -> apply_command_line_options().
+// The CPU block/mega-block/micro-block/nano-block/pico-block nest has no GPU meaning: its size
+// options are accepted and remembered but only the HIP tile shape (tuner / -hip_variant) matters.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <sstream>
+
+#include "ykh_runtime.hpp"
+
+namespace ykh {
+
+std::string version_string() { return "4.05.04-cdna4_hip"; }
+
+static inline idx_t ceil_div(idx_t a, idx_t b) { return (a + b - 1) / b; }
+
+bool Box::empty() const {
+    for (int d = 0; d < MAX_DOMAIN_DIMS; d++)
+        if (hi[d] <= lo[d]) return true;
+    return false;
+}
+
+// ------------------------------------------------------------------ Env
+Env::Env() {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        YKH_THROW("no HIP device is visible: the cdna4_hip kernel library needs an AMD GPU (there is no CPU fallback)");
+    (void)hipGetDevice(&device);
+}
+void Env::set_ranks(int r, int n) {
+    if (n < 1 || r < 0 || r >= n) YKH_THROW("invalid rank " + std::to_string(r) + " of " + std::to_string(n));
+    rank = r;
+    nranks = n;
+}
+static long long env_reduce(const Env& e, int op, long long v) {
+    if (e.nranks <= 1) return v;
+    if (!e.allreduce) YKH_THROW("multi-rank env has no all-reduce transport installed");
+    if (e.allreduce(e.user, op, &v) != 0) YKH_THROW("all-reduce transport failed");
+    return v;
+}
+long long Env::sum_over_ranks(long long v) const { return env_reduce(*this, 0, v); }
+long long Env::min_over_ranks(long long v) const { return env_reduce(*this, 1, v); }
+long long Env::max_over_ranks(long long v) const { return env_reduce(*this, 2, v); }
+
+// ------------------------------------------------------------------ Solution basics
+Solution::Solution(std::shared_ptr<Env> e, const SolnImpl& im) : env(e), impl(im), meta(im.meta) {
+    ndd = 0;
+    for (int i = 0; i < meta->ndims; i++) {
+        const DimMeta& d = meta->dims[i];
+        if (d.type == DIM_STEP) step_dim_name = d.name;
+        else if (d.type == DIM_DOMAIN) { domain_dim_names.push_back(d.name); ndd++; }
+        else misc_dim_names.push_back(d.name);
+    }
+    if (ndd > MAX_DOMAIN_DIMS) YKH_THROW("cdna4_hip runtime supports at most 3 domain dims");
+    for (int v = 0; v < meta->n_vars; v++) {
+        if (meta->vars[v].is_scratch) continue;
+        auto var = std::make_shared<Var>(this, &meta->vars[v], v);
+        vars.push_back(var);
+        var_map[var->name] = var;
+    }
+    part_variant.assign(impl.parts.size(), -1);
+    part_xchunk.assign(impl.parts.size(), 0);
+    YKH_HIP(hipStreamCreateWithFlags(&compute_stream, hipStreamNonBlocking));
+    YKH_HIP(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+    own_streams = true;
+    YKH_HIP(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
+    YKH_HIP(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
+}
+
+Solution::~Solution() {
+    free_halo_buffers();
+    vars.clear();
+    var_map.clear();
+    if (ev_a) (void)hipEventDestroy(ev_a);
+    if (ev_b) (void)hipEventDestroy(ev_b);
+    if (own_streams) {
+        if (compute_stream) (void)hipStreamDestroy(compute_stream);
+        if (comm_stream) (void)hipStreamDestroy(comm_stream);
+    }
+}
+
+void Solution::set_streams(hipStream_t c, hipStream_t m) {
+    if (own_streams) {
+        (void)hipStreamDestroy(compute_stream);
+        (void)hipStreamDestroy(comm_stream);
+        own_streams = false;
+    }
+    compute_stream = c;
+    comm_stream = m;
+}
+
+void Solution::synchronize() {
+    YKH_HIP(hipStreamSynchronize(compute_stream));
+    YKH_HIP(hipStreamSynchronize(comm_stream));
+}
+
+int Solution::domain_dim_idx(const std::string& dim, const char* fn) const {
+    for (int d = 0; d < ndd; d++)
+        if (domain_dim_names[d] == dim) return d;
+    YKH_THROW(std::string(fn) + ": '" + dim + "' is not a domain dimension of solution '" + meta->name + "'");
+}
+
+std::shared_ptr<Var> Solution::get_var(const std::string& name) const {
+    auto it = var_map.find(name);
+    if (it == var_map.end()) YKH_THROW("var '" + name + "' not found");
+    return it->second;
+}
+
+std::shared_ptr<Var> Solution::new_var(const std::string& name, const std::vector<std::string>& dims) {
+    if (var_map.count(name)) YKH_THROW("var '" + name + "' already exists");
+    auto v = std::make_shared<Var>(this, name, dims, (int)vars.size(), nullptr);
+    vars.push_back(v);
+    var_map[name] = v;
+    if (prepared) { v->compute_geometry(); }
+    return v;
+}
+
+std::shared_ptr<Var> Solution::new_fixed_size_var(const std::string& name, const std::vector<std::string>& dims,
+                                                  const std::vector<idx_t>& sizes) {
+    if (var_map.count(name)) YKH_THROW("var '" + name + "' already exists");
+    auto v = std::make_shared<Var>(this, name, dims, (int)vars.size(), &sizes);
+    vars.push_back(v);
+    var_map[name] = v;
+    v->compute_geometry();
+    v->allocate();   // fixed-size vars get storage immediately (new_var.cpp)
+    return v;
+}
+
+Box Solution::rank_box() const {
+    Box b;
+    for (int d = 0; d < MAX_DOMAIN_DIMS; d++) { b.lo[d] = 0; b.hi[d] = d < ndd ? local_size[d] : 1; }
+    return b;
+}
+
+// ------------------------------------------------------------------ command-line options
+// Same option names as KernelSettings::add_options (src/kernel/lib/settings.cpp:328-524); options
+// that only steer the CPU loop nest / OpenMP are accepted and recorded. Unknown tokens are returned
+// (soln_apis.cpp:297-313).
+namespace {
+struct OptSpec { const char* name; int kind; };   // kind: 0 bool, 1 int (per-dim family), 2 int, 3 double, 4 string
+bool parse_idx(const std::string& s, idx_t& v) {
+    if (s.empty()) return false;
+    char* end = nullptr;
+    long long x = strtoll(s.c_str(), &end, 10);
+    if (*end) return false;
+    v = x;
+    return true;
+}
+}  // namespace
+
+std::string Solution::apply_command_line_options(const std::vector<std::string>& args) {
+    std::vector<std::string> rem;
+    const char* dimfam_set[] = {"g", "l", "d", "b", "Mb", "mb", "nb", "pb", "mp", "ep", "nr", "ri", "r", "B", "sb"};
+    const char* bool_opts[] = {"overlap_comms", "use_shm", "use_device_mpi", "force_scalar_exchange", "force_scalar",
+                               "bind_inner_threads", "bundle_allocs", "init_scratch_vars", "auto_tune",
+                               "allow_addl_padding", "round_up_temporal_angles", "print_suffixes", "verbose",
+                               "exchange_halos", "auto_tune_each_stage", "trace"};
+    const char* int_opts[] = {"min_exterior", "max_threads", "outer_threads", "inner_threads", "numa_pref",
+                              "auto_tune_radius", "thread_divisor", "block_threads", "hip_xchunk", "device_thread_limit"};
+    const char* dbl_opts[] = {"auto_tune_trial_secs"};
+    const char* str_opts[] = {"auto_tune_targets", "hip_variant"};
+    for (size_t i = 0; i < args.size(); i++) {
+        const std::string& tok = args[i];
+        if (tok.size() < 2 || tok[0] != '-') { rem.push_back(tok); continue; }
+        std::string opt = tok.substr(1);
+        bool handled = false;
+        // booleans, with -no- prefix
+        {
+            bool val = true;
+            std::string b = opt;
+            if (b.rfind("no-", 0) == 0) { val = false; b = b.substr(3); }
+            for (auto bo : bool_opts)
+                if (b == bo) {
+                    handled = true;
+                    if (b == "overlap_comms") overlap_comms = val;
+                    else if (b == "exchange_halos") do_halo_exchange = val;
+                    else if (b == "force_scalar") { force_scalar = val; }
+                    else if (b == "auto_tune") auto_tune = val;
+                    else if (b == "trace") env->trace = val;
+                    else ignored_opts[b] = val ? "true" : "false";
+                }
+        }
+        if (handled) continue;
+        auto next_val = [&](std::string& out) -> bool {
+            if (i + 1 >= args.size()) return false;
+            out = args[++i];
+            return true;
+        };
+        for (auto io : int_opts)
+            if (opt == io) {
+                std::string v; idx_t n;
+                if (!next_val(v) || !parse_idx(v, n)) YKH_THROW("option '-" + opt + "' requires an integer value");
+                handled = true;
+                if (opt == "min_exterior") min_exterior = n;
+                else if (opt == "hip_xchunk") xchunk_override = n;
+                else ignored_opts[opt] = v;
+            }
+        if (handled) continue;
+        for (auto d : dbl_opts)
+            if (opt == d) {
+                std::string v;
+                if (!next_val(v)) YKH_THROW("option '-" + opt + "' requires a value");
+                auto_tune_trial_secs = atof(v.c_str());
+                handled = true;
+            }
+        if (handled) continue;
+        for (auto so : str_opts)
+            if (opt == so) {
+                std::string v;
+                if (!next_val(v)) YKH_THROW("option '-" + opt + "' requires a value");
+                if (opt == "hip_variant") variant_override = v;
+                else ignored_opts[opt] = v;
+                handled = true;
+            }
+        if (handled) continue;
+        // per-dim families: -g 64 (all dims), -gx 64 (one dim); -bt for the step dim of block sizes
+        for (auto fam : dimfam_set) {
+            std::string f(fam);
+            if (opt.rfind(f, 0) != 0) continue;
+            std::string dim = opt.substr(f.size());
+            int didx = -2;   // -2: no match, -1: all dims, >=0 domain dim, 100: step
+            if (dim.empty()) didx = -1;
+            else if (dim == step_dim_name && (f == "b" || f == "Mb")) didx = 100;
+            else
+                for (int d = 0; d < ndd; d++)
+                    if (dim == domain_dim_names[d]) didx = d;
+            if (didx == -2) continue;
+            std::string v; idx_t n;
+            if (!next_val(v) || !parse_idx(v, n)) YKH_THROW("option '-" + opt + "' requires an integer value");
+            handled = true;
+            auto apply = [&](int d) {
+                if (f == "g") { global_size[d] = n; rank_size[d] = 0; invalidate(); }
+                else if (f == "l" || f == "d") { rank_size[d] = n; global_size[d] = 0; invalidate(); }
+                else if (f == "b") block_size[d + 1] = n;
+                else if (f == "mp") { min_pad[d] = n; invalidate(); }
+                else if (f == "ep") { extra_pad[d] = n; invalidate(); }
+                else if (f == "nr") { num_ranks[d] = n; invalidate(); }
+                else if (f == "ri") { rank_index[d] = n; rank_index_set = true; invalidate(); }
+                else ignored_opts[f + domain_dim_names[d]] = v;
+            };
+            if (didx == 100) { if (f == "b") block_size[0] = n; else ignored_opts[opt] = v; }
+            else if (didx == -1) for (int d = 0; d < ndd; d++) apply(d);
+            else apply(didx);
+            break;
+        }
+        if (!handled) rem.push_back(tok);
+    }
+    std::string out;
+    for (size_t i = 0; i < rem.size(); i++) out += (i ? " " : "") + rem[i];
+    return out;
+}
+
+std::string Solution::get_command_line_help() const {
+    std::ostringstream os;
+    os << "Options of the cdna4_hip kernel library (names follow the YASK kernel options):\n"
+          " -g<dim> <n>   global-domain size      -l<dim> <n>  local-domain (per-rank) size\n"
+          " -nr<dim> <n>  number of ranks          -ri<dim> <n> this rank's index\n"
+          " -mp<dim> <n>  minimum padding          -ep<dim> <n> extra padding\n"
+          " -b<dim> <n>   block size (advisory; the HIP tile shape is what matters on the GPU)\n"
+          " -[no-]overlap_comms   overlap halo exchange with interior computation\n"
+          " -min_exterior <n>     minimum width of the exterior slabs\n"
+          " -[no-]exchange_halos  perform halo exchanges\n"
+          " -[no-]auto_tune       time the compiled HIP tile shapes at prepare_solution()\n"
+          " -auto_tune_trial_secs <s>\n"
+          " -[no-]force_scalar    use the generic one-thread-per-point kernel\n"
+          " -hip_variant <name>   force a kernel variant     -hip_xchunk <n>  x-march chunk length\n"
+          " CPU-only options (-Mb -mb -nb -pb -max_threads -outer_threads -inner_threads -numa_pref\n"
+          "  -bind_inner_threads -bundle_allocs -use_shm -use_device_mpi ...) are accepted and ignored.\n";
+    return os.str();
+}
+
+std::string Solution::get_command_line_values() const {
+    std::ostringstream os;
+    for (int d = 0; d < ndd; d++) os << " -g" << domain_dim_names[d] << " " << global_size[d];
+    for (int d = 0; d < ndd; d++) os << " -l" << domain_dim_names[d] << " " << (prepared ? local_size[d] : rank_size[d]);
+    for (int d = 0; d < ndd; d++) os << " -nr" << domain_dim_names[d] << " " << num_ranks[d];
+    for (int d = 0; d < ndd; d++) os << " -ri" << domain_dim_names[d] << " " << rank_index[d];
+    for (int d = 0; d < ndd; d++) os << " -b" << domain_dim_names[d] << " " << block_size[d + 1];
+    os << (overlap_comms ? " -overlap_comms" : " -no-overlap_comms") << " -min_exterior " << min_exterior
+       << (auto_tune ? " -auto_tune" : " -no-auto_tune") << (force_scalar ? " -force_scalar" : " -no-force_scalar");
+    for (size_t p = 0; p < impl.parts.size(); p++)
+        if (part_variant[p] >= 0) os << " -hip_variant[" << impl.parts[p].meta->name << "] " << impl.parts[p].variants[part_variant[p]].name;
+    return os.str();
+}
+
+// ------------------------------------------------------------------ rank grid (setup.cpp:169-524)
+// Most-compact factorisation: minimise the largest factor; candidates are visited with the factor
+// of dim 1 varying fastest and dim 0 derived (src/common/tuple.cpp:355-430), first best wins.
+static void compact_factors(idx_t N, int nd, idx_t* f) {
+    idx_t given = 1;
+    bool all = true;
+    for (int d = 0; d < nd; d++) { if (f[d] > 0) given *= f[d]; else all = false; }
+    if (all && given == N) return;
+    std::vector<idx_t> facts;
+    for (idx_t n = 1; n <= N; n++) if (N % n == 0) facts.push_back(n);
+    for (int keep = 1; keep >= 0; keep--) {
+        idx_t best[MAX_DOMAIN_DIMS] = {0, 0, 0};
+        idx_t best_max = -1;
+        // iterate dims 1..nd-1 over factors (dim 1 fastest), dim 0 computed
+        std::vector<size_t> ix(nd, 0);
+        while (true) {
+            idx_t can[MAX_DOMAIN_DIMS] = {1, 1, 1};
+            for (int d = 1; d < nd; d++) can[d] = (keep && f[d] > 0) ? f[d] : facts[ix[d]];
+            idx_t rest = 1;
+            for (int d = 1; d < nd; d++) rest *= can[d];
+            if (keep && f[0] > 0) can[0] = f[0];
+            else can[0] = (N % rest == 0) ? N / rest : 0;
+            idx_t prod = 1, mx = 0;
+            for (int d = 0; d < nd; d++) { prod *= can[d]; mx = std::max(mx, can[d]); }
+            if (can[0] > 0 && prod == N && (best_max < 0 || mx < best_max)) {
+                best_max = mx;
+                for (int d = 0; d < nd; d++) best[d] = can[d];
+            }
+            int d = 1;
+            for (; d < nd; d++) {
+                if (keep && f[d] > 0) continue;
+                if (++ix[d] < facts.size()) break;
+                ix[d] = 0;
+            }
+            if (d >= nd) break;
+        }
+        if (best_max >= 0) { for (int d = 0; d < nd; d++) f[d] = best[d]; return; }
+    }
+    YKH_THROW("cannot factor " + std::to_string(N) + " ranks over the domain dims");
+}
+
+void Solution::setup_rank() {
+    const idx_t nr = env->nranks;
+    idx_t f[MAX_DOMAIN_DIMS] = {1, 1, 1};
+    for (int d = 0; d < ndd; d++) f[d] = num_ranks[d];
+    compact_factors(nr, ndd, f);
+    idx_t prod = 1;
+    for (int d = 0; d < ndd; d++) prod *= f[d];
+    if (prod != nr) {
+        std::ostringstream os;
+        os << prod << " rank(s) requested (";
+        for (int d = 0; d < ndd; d++) os << (d ? " * " : "") << domain_dim_names[d] << "=" << f[d];
+        os << "), but " << nr << " rank(s) are active";
+        YKH_THROW(os.str());
+    }
+    for (int d = 0; d < ndd; d++) num_ranks[d] = f[d];
+    // rank id -> coords with the first domain dim varying fastest (Tuple::unlayout, first_inner)
+    if (!rank_index_set) {
+        idx_t me = env->rank;
+        for (int d = 0; d < ndd; d++) { rank_index[d] = me % num_ranks[d]; me /= num_ranks[d]; }
+    }
+    for (int d = 0; d < ndd; d++)
+        if (rank_index[d] < 0 || rank_index[d] >= num_ranks[d])
+            YKH_THROW("rank index of " + std::to_string(rank_index[d]) + " is not within allowed range [0 ... " +
+                      std::to_string(num_ranks[d] - 1) + "] in '" + domain_dim_names[d] + "' dimension on rank " +
+                      std::to_string(env->rank));
+    // sizes: either global or local given per dim (setup.cpp:453-495)
+    for (int d = 0; d < ndd; d++) {
+        if (global_size[d] > 0 && rank_size[d] == 0) {
+            idx_t base = ceil_div(global_size[d], num_ranks[d]);
+            idx_t last = global_size[d] - base * (num_ranks[d] - 1);
+            if (last <= 0)
+                YKH_THROW("global-domain size " + std::to_string(global_size[d]) + " in '" + domain_dim_names[d] +
+                          "' cannot be split over " + std::to_string(num_ranks[d]) + " ranks");
+            local_size[d] = (rank_index[d] == num_ranks[d] - 1) ? last : base;
+            rank_ofs[d] = rank_index[d] * base;
+        } else if (rank_size[d] > 0) {
+            local_size[d] = rank_size[d];
+            // every rank in a grid line must use the same size for the offsets to be derivable locally
+            rank_ofs[d] = rank_index[d] * rank_size[d];
+            global_size[d] = rank_size[d] * num_ranks[d];
+        } else {
+            YKH_THROW("both local-domain size and global-domain size are zero in '" + domain_dim_names[d] +
+                      "' dimension on rank " + std::to_string(env->rank) +
+                      "; specify one, and the other will be calculated");
+        }
+    }
+    // neighbours
+    neighbors.clear();
+    int nloop[3] = {ndd > 0 ? 3 : 1, ndd > 1 ? 3 : 1, ndd > 2 ? 3 : 1};
+    for (int a = 0; a < nloop[0]; a++)
+        for (int b = 0; b < nloop[1]; b++)
+            for (int c = 0; c < nloop[2]; c++) {
+                int o[3] = {nloop[0] > 1 ? a - 1 : 0, nloop[1] > 1 ? b - 1 : 0, nloop[2] > 1 ? c - 1 : 0};
+                if (!o[0] && !o[1] && !o[2]) continue;
+                idx_t co[3];
+                bool ok = true;
+                for (int d = 0; d < ndd; d++) {
+                    co[d] = rank_index[d] + o[d];
+                    if (co[d] < 0 || co[d] >= num_ranks[d]) ok = false;
+                }
+                if (!ok) continue;
+                idx_t id = 0;
+                for (int d = ndd - 1; d >= 0; d--) id = id * num_ranks[d] + co[d];
+                Neighbor nb;
+                nb.rank = (int)id;
+                nb.l1 = 0;
+                for (int d = 0; d < MAX_DOMAIN_DIMS; d++) { nb.ofs[d] = d < ndd ? o[d] : 0; nb.l1 += std::abs(nb.ofs[d]); }
+                neighbors.push_back(nb);
+            }
+}
+
+// ------------------------------------------------------------------ prepare / end
+void Solution::prepare() {
+    for (auto& h : before_prepare) h(*this);
+    setup_rank();
+    // solution-wide pads = max halo over all vars (see Var::compute_geometry)
+    for (int d = 0; d < ndd; d++) {
+        shared_pad_l_[d] = shared_pad_r_[d] = 0;
+        for (auto& v : vars) {
+            if (v->fixed_size || !v->uses_domain[d]) continue;
+            shared_pad_l_[d] = std::max({shared_pad_l_[d], v->halo_l[d], v->min_pad_l[d]});
+            shared_pad_r_[d] = std::max({shared_pad_r_[d], v->halo_r[d], v->min_pad_r[d]});
+        }
+    }
+    for (int d = 0; d < ndd; d++) {
+        idx_t need = std::max(shared_pad_l_[d], shared_pad_r_[d]);
+        if (num_ranks[d] > 1 && local_size[d] < need)
+            YKH_THROW("local-domain size of " + std::to_string(local_size[d]) + " in '" + domain_dim_names[d] +
+                      "' dim is less than the required halo size of " + std::to_string(need));
+    }
+    for (auto& v : vars) {
+        if (v->fixed_size) continue;
+        // keep existing storage only if the geometry is unchanged
+        idx_t old_slot = v->slot_elems, old_ofs = v->origin_elems;
+        idx_t old_stride[3] = {v->stride[0], v->stride[1], v->stride[2]};
+        v->compute_geometry();
+        bool same = v->is_allocated() && old_slot == v->slot_elems && old_ofs == v->origin_elems &&
+                    old_stride[0] == v->stride[0] && old_stride[1] == v->stride[1] && old_stride[2] == v->stride[2];
+        if (!same) v->allocate();
+        v->set_dirty_all(true);
+    }
+    free_halo_buffers();
+    alloc_halo_buffers();
+    // interior box for comm/compute overlap (alloc.cpp:686-723 `mpi_interior`)
+    interior_box = rank_box();
+    have_interior = false;
+    if (env->nranks > 1) {
+        for (int d = 0; d < ndd; d++) {
+            idx_t w = std::max<idx_t>(std::max(shared_pad_l_[d], shared_pad_r_[d]), min_exterior);
+            bool left = rank_index[d] > 0, right = rank_index[d] < num_ranks[d] - 1;
+            if (left) interior_box.lo[d] += w;
+            if (right) interior_box.hi[d] -= w;
+        }
+        have_interior = !interior_box.empty();
+    }
+    // kernel variants
+    for (size_t p = 0; p < impl.parts.size(); p++) {
+        const PartImpl& pi = impl.parts[p];
+        int v = pi.default_variant;
+        if (force_scalar) v = 0;
+        if (!variant_override.empty()) {
+            bool found = false;
+            for (size_t k = 0; k < pi.variants.size(); k++)
+                if (variant_override == pi.variants[k].name) { v = (int)k; found = true; }
+            if (!found && impl.parts.size() == 1) {
+                std::string names;
+                for (auto& kv : pi.variants) names += std::string(" ") + kv.name;
+                YKH_THROW("unknown -hip_variant '" + variant_override + "'; available:" + names);
+            }
+        }
+        part_variant[p] = v;
+        part_xchunk[p] = xchunk_override;
+    }
+    stats = Stats();
+    prepared = true;
+    if (auto_tune) run_auto_tuner_now();
+    for (auto& h : after_prepare) h(*this);
+}
+
+void Solution::end() {
+    synchronize();
+    free_halo_buffers();
+    for (auto& v : vars) v->release();
+    prepared = false;
+}
+
+// ------------------------------------------------------------------ launches
+void Solution::fill_part_args(int part, idx_t t, const Box& box, PartArgs& a) const {
+    const PartMeta& pm = *impl.parts[part].meta;
+    std::memset(&a, 0, sizeof(a));
+    if (pm.n_groups > MAX_GROUPS) YKH_THROW("part has too many access groups");
+    const Var* full = nullptr;
+    for (int g = 0; g < pm.n_groups; g++) {
+        const AccessGroup& ag = pm.groups[g];
+        const Var* v = nullptr;
+        for (auto& vv : vars) if (vv->meta == &meta->vars[ag.var]) v = vv.get();
+        if (!v || !v->is_allocated()) YKH_THROW("var used by part '" + std::string(pm.name) + "' has no storage");
+        a.ptr[g] = v->slot_base(ag.has_step ? t + ag.dt : 0);
+        a.gsx[g] = v->stride[0];
+        a.gsy[g] = v->stride[1];
+        a.gsz[g] = (int)v->stride[2];
+        bool is_full = true;
+        for (int d = 0; d < ndd; d++) is_full &= v->uses_domain[d];
+        if (is_full && !v->fixed_size && !full) full = v;
+    }
+    if (ndd == 3 && full) {
+        a.sx = full->stride[0];
+        a.sy = full->stride[1];
+        a.ax0 = (int)-full->pad_l[0]; a.ax1 = (int)(full->dom_size[0] + full->pad_r[0]);
+        a.ay0 = (int)-full->pad_l[1]; a.ay1 = (int)(full->dom_size[1] + full->pad_r[1]);
+        a.az0 = (int)-full->pad_l[2]; a.az1 = (int)(full->dom_size[2] + full->pad_r[2]);
+    }
+    // boxes are expressed in (x,y,z) = domain_idx (0,1,2); solutions with fewer dims use size-1 boxes
+    a.x0 = (int)box.lo[0]; a.x1 = (int)box.hi[0];
+    a.y0 = (int)box.lo[1]; a.y1 = (int)box.hi[1];
+    a.z0 = (int)box.lo[2]; a.z1 = (int)box.hi[2];
+    a.ofs_x = (int)rank_ofs[0]; a.ofs_y = (int)rank_ofs[1]; a.ofs_z = (int)rank_ofs[2];
+    a.t = t;
+}
+
+void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t, const Box& box, hipStream_t s) {
+    if (box.empty()) return;
+    const KernelVariant& kv = impl.parts[part].variants[variant];
+    PartArgs a;
+    fill_part_args(part, t, box, a);
+    if (kv.star) {
+        const int vz = 16 / elem_bytes();
+        idx_t zt0 = box.lo[2] & ~(idx_t)(vz - 1);
+        a.ntz = (int)ceil_div(box.hi[2] - zt0, kv.tz);
+        a.nty = (int)ceil_div(box.hi[1] - box.lo[1], kv.ty);
+        idx_t nx = box.hi[0] - box.lo[0];
+        idx_t xc = xchunk;
+        if (xc <= 0) {
+            // default: march the whole box unless that leaves the chip short of workgroups
+            idx_t tiles = (idx_t)a.ntz * a.nty;
+            idx_t want = 1024;
+            idx_t nchunks = std::max<idx_t>(1, std::min<idx_t>(ceil_div(want, tiles), ceil_div(nx, 64)));
+            xc = ceil_div(nx, nchunks);
+        }
+        xc = std::max<idx_t>(1, std::min(xc, nx));
+        a.xchunk = (int)xc;
+        a.nxc = (int)ceil_div(nx, xc);
+        dim3 grid((unsigned)((idx_t)a.ntz * a.nty * a.nxc), 1, 1);
+        kv.launch(a, grid, s);
+    } else {
+        dim3 grid((unsigned)ceil_div(box.hi[2] - box.lo[2], 64), (unsigned)ceil_div(box.hi[1] - box.lo[1], 4),
+                  (unsigned)(box.hi[0] - box.lo[0]));
+        kv.launch(a, grid, s);
+    }
+    YKH_HIP(hipGetLastError());
+}
+
+void Solution::launch_part(int part, idx_t t, const Box& box, hipStream_t s) {
+    launch_part_variant(part, part_variant[part], part_xchunk[part], t, box, s);
+}
+
+// ------------------------------------------------------------------ run
+void Solution::run(idx_t first_step, idx_t last_step) {
+    for (auto& h : before_run) h(*this, first_step, last_step);
+    if (!prepared) YKH_THROW("run_solution() called without calling prepare_solution() first");
+    const idx_t dir = (last_step >= first_step) ? 1 : -1;
+    if (dir != meta->step_dir)
+        YKH_THROW("run_solution() step direction does not match the direction in which solution '" +
+                  std::string(meta->name) + "' was defined");
+    auto t0 = std::chrono::steady_clock::now();
+    const bool multi = env->nranks > 1 && do_halo_exchange && !neighbors.empty();
+    double halo_secs = 0;
+    if (multi) {
+        // other ranks may have changed data through the API: treat every var as possibly dirty
+        // (set_all_neighbor_vars_dirty, context.cpp:234) so that all ranks agree on message sizes
+        for (auto& v : vars) v->set_dirty_all(true);
+        auto h0 = std::chrono::steady_clock::now();
+        exchange_halos_all();   // initial exchange of everything marked dirty (context.cpp:346)
+        halo_secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - h0).count();
+    }
+    const Box rb = rank_box();
+    idx_t nsteps = 0;
+    for (idx_t t = first_step; dir > 0 ? t <= last_step : t >= last_step; t += dir) {
+        for (int st = 0; st < meta->n_stages; st++) {
+            const StageMeta& sm = meta->stages[st];
+            const bool overlap = multi && overlap_comms && have_interior;
+            if (overlap) {
+                // exterior slabs first (context.cpp:377-444), then start the exchange, then the interior
+                Box rem = rb;
+                for (int d = 0; d < ndd; d++) {
+                    if (interior_box.lo[d] > rem.lo[d]) {
+                        Box s = rem; s.hi[d] = interior_box.lo[d];
+                        for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, s, compute_stream);
+                        rem.lo[d] = interior_box.lo[d];
+                    }
+                    if (interior_box.hi[d] < rem.hi[d]) {
+                        Box s = rem; s.lo[d] = interior_box.hi[d];
+                        for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, s, compute_stream);
+                        rem.hi[d] = interior_box.hi[d];
+                    }
+                }
+            } else {
+                for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, rb, compute_stream);
+            }
+            // bookkeeping: written vars become valid at the output step and dirty for neighbours
+            for (int k = 0; k < sm.n_parts; k++) {
+                const PartMeta& pm = *impl.parts[sm.parts[k]].meta;
+                for (int w = 0; w < pm.n_writes; w++) {
+                    const AccessGroup& ag = pm.groups[pm.writes[w]];
+                    for (auto& v : vars)
+                        if (v->meta == &meta->vars[ag.var]) {
+                            if (ag.has_step) { v->update_valid_step(t + ag.dt); v->set_dirty(true, t + ag.dt); }
+                            else v->set_dirty_all(true);
+                        }
+                }
+            }
+            if (multi) {
+                exchange_halos(t, st, /*start_only=*/true, false);
+                if (overlap)
+                    for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, interior_box, compute_stream);
+                exchange_halos(t, st, false, /*finish_only=*/true);
+            }
+        }
+        nsteps++;
+    }
+    YKH_HIP(hipStreamSynchronize(compute_stream));
+    if (multi) YKH_HIP(hipStreamSynchronize(comm_stream));
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    stats.elapsed_secs += secs;
+    stats.halo_secs += halo_secs;
+    stats.num_steps_done += nsteps;
+    steps_done_total += nsteps;
+    for (auto& h : after_run) h(*this, first_step, last_step);
+}
+
+// ------------------------------------------------------------------ stats (soln_apis.cpp:349-562)
+Stats Solution::get_stats() {
+    Stats s = stats;
+    idx_t pts = 1, lpts = 1;
+    for (int d = 0; d < ndd; d++) { pts *= global_size[d]; lpts *= local_size[d]; }
+    s.num_elements = pts;
+    idx_t reads = 0, writes = 0, fpops = 0;
+    for (auto& p : impl.parts) { reads += p.meta->points_read; writes += p.meta->points_written; fpops += p.meta->fp_ops; }
+    s.num_writes_done = writes * pts * s.num_steps_done;
+    s.num_reads_done = reads * pts * s.num_steps_done;
+    s.est_fp_ops_done = fpops * pts * s.num_steps_done;
+    s.pts_per_sec = s.elapsed_secs > 0 ? (double)pts * (double)s.num_steps_done / s.elapsed_secs : 0.0;
+    stats = Stats();   // cleared on read, like the reference
+    return s;
+}
+
+// ------------------------------------------------------------------ auto-tuner
+// The reference tunes CPU block sizes by timing steps (auto_tuner.cpp:206-434). Here the search
+// space is the list of compiled HIP tile shapes (x the x-march chunk); each candidate is timed on
+// scratch copies of the written step slots so that solution data is left untouched.
+void Solution::reset_auto_tuner(bool enable) { auto_tune = enable; }
+
+void Solution::run_auto_tuner_now() {
+    if (!prepared) YKH_THROW("run_auto_tuner_now() called without calling prepare_solution() first");
+    hipEvent_t e0, e1;
+    YKH_HIP(hipEventCreate(&e0));
+    YKH_HIP(hipEventCreate(&e1));
+    const Box rb = rank_box();
+    // save every var (tuning runs real kernels, which update written vars in place)
+    std::vector<void*> saves(vars.size(), nullptr);
+    for (size_t i = 0; i < vars.size(); i++)
+        if (vars[i]->is_allocated() && vars[i]->is_written) {
+            YKH_HIP(hipMalloc(&saves[i], vars[i]->bytes()));
+            YKH_HIP(hipMemcpyAsync(saves[i], vars[i]->dptr, vars[i]->bytes(), hipMemcpyDeviceToDevice, compute_stream));
+        }
+    for (size_t p = 0; p < impl.parts.size(); p++) {
+        const PartImpl& pi = impl.parts[p];
+        double best = 1e30;
+        int best_v = part_variant[p];
+        idx_t best_xc = part_xchunk[p];
+        for (size_t k = 0; k < pi.variants.size(); k++) {
+            if (!pi.variants[k].star && pi.variants.size() > 1 && !force_scalar) continue;   // naive only as last resort
+            std::vector<idx_t> chunks = {0};
+            if (pi.variants[k].star) { chunks.push_back(rb.hi[0] - rb.lo[0]); chunks.push_back(256); chunks.push_back(128); }
+            for (idx_t xc : chunks) {
+                launch_part_variant((int)p, (int)k, xc, 0, rb, compute_stream);   // warm-up
+                YKH_HIP(hipEventRecord(e0, compute_stream));
+                int reps = 0;
+                float ms = 0;
+                do {
+                    launch_part_variant((int)p, (int)k, xc, 0, rb, compute_stream);
+                    reps++;
+                    YKH_HIP(hipEventRecord(e1, compute_stream));
+                    YKH_HIP(hipEventSynchronize(e1));
+                    YKH_HIP(hipEventElapsedTime(&ms, e0, e1));
+                } while (ms * 1e-3 < auto_tune_trial_secs && reps < 50);
+                double per = ms / reps;
+                if (env->trace) fprintf(stderr, "auto-tuner: part %s variant %s xchunk %lld: %.4f ms\n", pi.meta->name,
+                                        pi.variants[k].name, (long long)xc, per);
+                if (per < best) { best = per; best_v = (int)k; best_xc = xc; }
+            }
+        }
+        // all ranks must agree: take the choice of the slowest rank's best? keep it simple and
+        // deterministic -- every rank times the same shapes on the same sizes; ties are rare.
+        part_variant[p] = best_v;
+        part_xchunk[p] = best_xc;
+    }
+    for (size_t i = 0; i < vars.size(); i++)
+        if (saves[i]) {
+            YKH_HIP(hipMemcpyAsync(vars[i]->dptr, saves[i], vars[i]->bytes(), hipMemcpyDeviceToDevice, compute_stream));
+        }
+    YKH_HIP(hipStreamSynchronize(compute_stream));
+    for (auto s : saves) if (s) (void)hipFree(s);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+}
+
+idx_t Solution::compare_data(const Solution& ref, double eps) const {
+    idx_t bad = 0;
+    if (vars.size() != ref.vars.size()) return 1;
+    for (size_t i = 0; i < vars.size(); i++) bad += vars[i]->compare(*ref.vars[i], eps);
+    return bad;
+}
+
+}  // namespace ykh

@@ -1,0 +1,43 @@
+// ykh_stencil_tu.hpp -- helpers used by the per-stencil translation unit (stencil_<name>.hip) to
+// instantiate kernel variants for the parts emitted by the `cdna4_hip` compiler target and to
+// register them with the runtime (ykh_solution_impl()).
+#pragma once
+#include <string>
+
+#include "ykh_device.hpp"
+#include "ykh_runtime.hpp"
+
+namespace ykh {
+
+template <class P>
+void launch_naive(const PartArgs& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((naive_kernel<P>), grid, dim3(256), 0, s, a);
+}
+
+template <class P, int TZL, int TYL, int RY, int ROT>
+void launch_star(const PartArgs& a, dim3 grid, hipStream_t s) {
+    typedef Star25dCfg<P, TZL, TYL, RY, ROT> C;
+    static bool attr_set = false;
+    if (!attr_set) {
+        // allow more than the default 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&star25d_kernel<P, TZL, TYL, RY, ROT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((star25d_kernel<P, TZL, TYL, RY, ROT>), grid, dim3(C::NT), C::lds_bytes, s, a);
+}
+
+template <class P>
+KernelVariant naive_variant() {
+    return KernelVariant{"naive", false, 64, 4, 0, 256, &launch_naive<P>};
+}
+
+template <class P, int TZL, int TYL, int RY, int ROT>
+KernelVariant star_variant() {
+    typedef Star25dCfg<P, TZL, TYL, RY, ROT> C;
+    static const std::string name = "star25d_z" + std::to_string(C::TZ) + "_y" + std::to_string(C::TY) + "_r" +
+                                    std::to_string(RY) + (ROT == ROT_UNROLL ? "_u" : "_m");
+    return KernelVariant{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_star<P, TZL, TYL, RY, ROT>};
+}
+
+}  // namespace ykh

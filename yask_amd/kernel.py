@@ -1,0 +1,417 @@
+"""Python face of the cdna4_hip YASK kernel library.
+
+Mirrors the classes and method names of the reference's SWIG module `yask_kernel`
+(src/kernel/swig/yask_kernel_api.i over include/yask_kernel_api.hpp, include/aux/yk_solution_api.hpp,
+include/aux/yk_var_api.hpp): `yk_factory`, `yk_env`, `yk_solution`, `yk_var`, `yk_stats`.  Errors raise
+`RuntimeError` whose text starts with "YASK error: ", exactly as the SWIG wrapper maps
+yask::yask_exception (yask_kernel_api.i:75-82).  Every call goes through the C ABI
+(include/yask_hip_c_api.h) of libyask_kernel.<stencil>.cdna4_hip.so; numpy arrays stand in for the
+SWIG `pybuffer` slices.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+
+idx_t = _capi.idx_t
+
+
+def _b(s):
+    return s.encode() if isinstance(s, str) else s
+
+
+class _Lib:
+    """A loaded kernel library + error translation."""
+
+    def __init__(self, stencil):
+        self.stencil = stencil
+        self.c = _capi.load(stencil)
+
+    def check(self):
+        if self.c.yk_last_error_code():
+            msg = self.c.yk_last_error().decode()
+            self.c.yk_clear_error()
+            raise RuntimeError(msg)
+
+    def call(self, name, *args):
+        r = getattr(self.c, name)(*args)
+        self.check()
+        return r
+
+    def call_rc(self, name, *args):
+        rc = getattr(self.c, name)(*args)
+        if rc != 0:
+            self.check()
+            raise RuntimeError("YASK error: %s failed" % name)
+        return rc
+
+
+class yk_stats:
+    """yk_stats (include/aux/yk_solution_api.hpp:1300-1348)."""
+
+    def __init__(self, st):
+        self._st = st
+
+    def get_num_elements(self): return int(self._st.num_elements)
+    def get_num_steps_done(self): return int(self._st.num_steps_done)
+    def get_num_writes_done(self): return int(self._st.num_writes_done)
+    def get_est_fp_ops_done(self): return int(self._st.est_fp_ops_done)
+    def get_elapsed_secs(self): return float(self._st.elapsed_secs)
+    # extensions
+    def get_num_reads_done(self): return int(self._st.num_reads_done)
+    def get_halo_secs(self): return float(self._st.halo_secs)
+    def get_points_per_sec(self): return float(self._st.points_per_sec)
+
+
+class yk_reduction_result:
+    def __init__(self, r):
+        self._r = r
+
+    def get_reduction_mask(self): return int(self._r.reduction_mask)
+    def get_num_elements_reduced(self): return int(self._r.num_elements_reduced)
+    def get_sum(self): return float(self._r.sum)
+    def get_sum_squares(self): return float(self._r.sum_squares)
+    def get_product(self): return float(self._r.product)
+    def get_max(self): return float(self._r.max)
+    def get_min(self): return float(self._r.min)
+
+
+class yk_var:
+    """yk_var (include/aux/yk_var_api.hpp:185-1490). Indices are overall-domain (global) indices in
+    the var's own dim order; slice bounds are inclusive."""
+
+    yk_sum_reduction, yk_sum_squares_reduction, yk_product_reduction, yk_max_reduction, yk_min_reduction = 1, 2, 4, 8, 16
+
+    def __init__(self, lib, h, soln):
+        self._lib, self._h, self._soln = lib, h, soln
+
+    def _idx(self, v):
+        v = list(v)
+        n = self.get_num_dims()
+        if len(v) != n:
+            raise RuntimeError("YASK error: %d indices provided for var '%s' with %d dims" % (len(v), self.get_name(), n))
+        return (idx_t * n)(*[int(x) for x in v])
+
+    def get_name(self): return self._lib.call("yk_var_get_name", self._h).decode()
+    def get_num_dims(self): return self._lib.call("yk_var_get_num_dims", self._h)
+    def get_dim_names(self): return [self._lib.call("yk_var_get_dim_name", self._h, i).decode() for i in range(self.get_num_dims())]
+    def get_num_domain_dims(self):
+        dd = self._soln.get_domain_dim_names()
+        return sum(1 for d in self.get_dim_names() if d in dd)
+    def is_dim_used(self, dim): return bool(self._lib.call("yk_var_is_dim_used", self._h, _b(dim)))
+    def is_fixed_size(self): return bool(self._lib.call("yk_var_is_fixed_size", self._h))
+    def get_first_valid_step_index(self): return self._lib.call("yk_var_get_first_valid_step_index", self._h)
+    def get_last_valid_step_index(self): return self._lib.call("yk_var_get_last_valid_step_index", self._h)
+
+    def _vecget(self, fn):
+        return [fn(d) for d in self.get_dim_names()]
+
+    def get_first_local_index_vec(self): return self._vecget(self.get_first_local_index)
+    def get_last_local_index_vec(self): return self._vecget(self.get_last_local_index)
+    def get_alloc_size_vec(self): return self._vecget(self.get_alloc_size)
+    def _domvec(self, fn): return [fn(d) for d in self.get_dim_names() if d in self._soln.get_domain_dim_names()]
+    def get_rank_domain_size_vec(self): return self._domvec(self.get_rank_domain_size)
+    def get_first_rank_domain_index_vec(self): return self._domvec(self.get_first_rank_domain_index)
+    def get_last_rank_domain_index_vec(self): return self._domvec(self.get_last_rank_domain_index)
+    def get_first_rank_halo_index_vec(self): return self._domvec(self.get_first_rank_halo_index)
+    def get_last_rank_halo_index_vec(self): return self._domvec(self.get_last_rank_halo_index)
+
+    def are_indices_local(self, indices): return bool(self._lib.call("yk_var_are_indices_local", self._h, self._idx(indices)))
+    def get_element(self, indices): return self._lib.call("yk_var_get_element", self._h, self._idx(indices))
+    def set_element(self, val, indices, strict_indices=True):
+        return self._lib.call("yk_var_set_element", self._h, float(val), self._idx(indices), int(strict_indices))
+    def add_to_element(self, val, indices, strict_indices=True):
+        return self._lib.call("yk_var_add_to_element", self._h, float(val), self._idx(indices), int(strict_indices))
+
+    def _np_dtype(self):
+        return np.float32 if self._soln.get_element_bytes() == 4 else np.float64
+
+    def get_elements_in_slice(self, first_indices, last_indices, buffer=None):
+        """Returns a numpy array shaped (last-first+1) per dim (row-major, var dim order).
+        With `buffer` (a writable float32/float64 array) fills it like the C++ overloads."""
+        f, l = list(first_indices), list(last_indices)
+        shape = [int(b) - int(a) + 1 for a, b in zip(f, l)]
+        if buffer is None:
+            buffer = np.empty(shape, dtype=self._np_dtype())
+        if buffer.dtype not in (np.float32, np.float64) or not buffer.flags.c_contiguous:
+            raise RuntimeError("YASK error: get_elements_in_slice needs a C-contiguous float32/float64 buffer")
+        fn = "yk_var_get_elements_in_slice_f32" if buffer.dtype == np.float32 else "yk_var_get_elements_in_slice_f64"
+        self._lib.call(fn, self._h, buffer.ctypes.data_as(C.c_void_p), buffer.size, self._idx(f), self._idx(l))
+        return buffer
+
+    def set_elements_in_slice(self, buffer, first_indices, last_indices):
+        a = np.ascontiguousarray(buffer)
+        if a.dtype not in (np.float32, np.float64):
+            a = a.astype(self._np_dtype())
+        fn = "yk_var_set_elements_in_slice_f32" if a.dtype == np.float32 else "yk_var_set_elements_in_slice_f64"
+        return self._lib.call(fn, self._h, a.ctypes.data_as(C.c_void_p), a.size, self._idx(first_indices), self._idx(last_indices))
+
+    def set_elements_in_slice_same(self, val, first_indices, last_indices, strict_indices=True):
+        return self._lib.call("yk_var_set_elements_in_slice_same", self._h, float(val), self._idx(first_indices),
+                              self._idx(last_indices), int(strict_indices))
+
+    def set_all_elements_same(self, val): self._lib.call_rc("yk_var_set_all_elements_same", self._h, float(val))
+
+    def reduce_elements_in_slice(self, reduction_mask, first_indices, last_indices, strict_indices=True):
+        r = _capi.YkReduction()
+        self._lib.call_rc("yk_var_reduce_elements_in_slice", self._h, int(reduction_mask), self._idx(first_indices),
+                          self._idx(last_indices), int(strict_indices), C.byref(r))
+        return yk_reduction_result(r)
+
+    def format_indices(self, indices):
+        return ", ".join("%s=%d" % (d, i) for d, i in zip(self.get_dim_names(), indices))
+
+    def get_halo_exchange_l1_norm(self): return self._lib.call("yk_var_get_halo_exchange_l1_norm", self._h)
+    def set_halo_exchange_l1_norm(self, n): self._lib.call_rc("yk_var_set_halo_exchange_l1_norm", self._h, int(n))
+    def is_dynamic_step_alloc(self): return bool(self._lib.call("yk_var_is_dynamic_step_alloc", self._h))
+    def is_storage_allocated(self): return bool(self._lib.call("yk_var_is_storage_allocated", self._h))
+    def get_num_storage_bytes(self): return self._lib.call("yk_var_get_num_storage_bytes", self._h)
+    def get_num_storage_elements(self): return self._lib.call("yk_var_get_num_storage_elements", self._h)
+    def alloc_storage(self): self._lib.call_rc("yk_var_alloc_storage", self._h)
+    def release_storage(self): self._lib.call_rc("yk_var_release_storage", self._h)
+    def is_storage_layout_identical(self, other): return bool(self._lib.call("yk_var_is_storage_layout_identical", self._h, other._h))
+    def fuse_vars(self, source): self._lib.call_rc("yk_var_fuse_vars", self._h, source._h)
+    def get_raw_storage_buffer(self): return self._lib.call("yk_var_get_raw_storage_buffer", self._h)
+    def get_device_storage(self): return self._lib.call("yk_var_get_device_storage", self._h)
+    # extension (not in the reference API): layout-independent deterministic init
+    def set_elements_hash(self, offset=0.0, scale=1.0, hash_id=0):
+        self._lib.call_rc("yk_var_set_elements_hash", self._h, float(offset), float(scale), int(hash_id))
+
+
+def _dim_getter(cname):
+    def f(self, dim):
+        return self._lib.call(cname, self._h, _b(dim))
+    return f
+
+
+def _dim_setter(cname):
+    def f(self, dim, n):
+        self._lib.call_rc(cname, self._h, _b(dim), int(n))
+    return f
+
+
+for _n in ["first_local_index", "last_local_index", "alloc_size", "rank_domain_size", "first_rank_domain_index",
+           "last_rank_domain_index", "left_halo_size", "right_halo_size", "first_rank_halo_index", "last_rank_halo_index",
+           "left_pad_size", "right_pad_size", "left_extra_pad_size", "right_extra_pad_size", "first_misc_index",
+           "last_misc_index"]:
+    setattr(yk_var, "get_" + _n, _dim_getter("yk_var_get_" + _n))
+for _n in ["left_min_pad_size", "right_min_pad_size", "min_pad_size", "left_halo_size", "right_halo_size", "halo_size",
+           "first_misc_index", "alloc_size"]:
+    setattr(yk_var, "set_" + _n, _dim_setter("yk_var_set_" + _n))
+
+
+class yk_solution:
+    """yk_solution (include/aux/yk_solution_api.hpp:82-1292)."""
+
+    def __init__(self, lib, h, env):
+        self._lib, self._h, self._env = lib, h, env
+        self._vars = {}
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.c.yk_free_solution(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def get_name(self): return self._lib.call("yk_solution_get_name", self._h).decode()
+    def get_description(self): return self._lib.call("yk_solution_get_description", self._h).decode()
+    def get_target(self): return self._lib.call("yk_solution_get_target", self._h).decode()
+    def is_offloaded(self): return bool(self._lib.call("yk_solution_is_offloaded", self._h))
+    def get_element_bytes(self): return self._lib.call("yk_solution_get_element_bytes", self._h)
+    def get_step_dim_name(self): return self._lib.call("yk_solution_get_step_dim_name", self._h).decode()
+    def get_num_domain_dims(self): return self._lib.call("yk_solution_get_num_domain_dims", self._h)
+    def get_domain_dim_names(self):
+        return [self._lib.call("yk_solution_get_domain_dim_name", self._h, i).decode() for i in range(self.get_num_domain_dims())]
+    def get_misc_dim_names(self):
+        n = self._lib.call("yk_solution_get_num_misc_dims", self._h)
+        return [self._lib.call("yk_solution_get_misc_dim_name", self._h, i).decode() for i in range(n)]
+
+    def _vec_set(self, setter, vals):
+        dd = self.get_domain_dim_names()
+        vals = list(vals)
+        if len(vals) != len(dd):
+            raise RuntimeError("YASK error: %d values provided for %d domain dims" % (len(vals), len(dd)))
+        for d, v in zip(dd, vals):
+            setter(d, v)
+
+    def set_rank_domain_size_vec(self, vals): self._vec_set(self.set_rank_domain_size, vals)
+    def get_rank_domain_size_vec(self): return [self.get_rank_domain_size(d) for d in self.get_domain_dim_names()]
+    def set_overall_domain_size_vec(self, vals): self._vec_set(self.set_overall_domain_size, vals)
+    def get_overall_domain_size_vec(self): return [self.get_overall_domain_size(d) for d in self.get_domain_dim_names()]
+    def set_num_ranks_vec(self, vals): self._vec_set(self.set_num_ranks, vals)
+    def get_num_ranks_vec(self): return [self.get_num_ranks(d) for d in self.get_domain_dim_names()]
+    def set_rank_index_vec(self, vals): self._vec_set(self.set_rank_index, vals)
+    def get_rank_index_vec(self): return [self.get_rank_index(d) for d in self.get_domain_dim_names()]
+    def set_block_size_vec(self, vals): self._vec_set(self.set_block_size, vals)
+    def get_block_size_vec(self): return [self.get_block_size(d) for d in self.get_domain_dim_names()]
+    def get_first_rank_domain_index_vec(self): return [self.get_first_rank_domain_index(d) for d in self.get_domain_dim_names()]
+    def get_last_rank_domain_index_vec(self): return [self.get_last_rank_domain_index(d) for d in self.get_domain_dim_names()]
+    def get_num_outer_threads(self): return 1
+    def get_num_inner_threads(self): return 1
+
+    def apply_command_line_options(self, args):
+        if not isinstance(args, str):
+            args = " ".join(args)
+        buf = C.create_string_buffer(4096)
+        self._lib.call_rc("yk_solution_apply_command_line_options", self._h, _b(args), buf, 4096)
+        return buf.value.decode()
+
+    def get_command_line_help(self): return self._lib.call("yk_solution_get_command_line_help", self._h).decode()
+    def get_command_line_values(self): return self._lib.call("yk_solution_get_command_line_values", self._h).decode()
+    def get_num_vars(self): return self._lib.call("yk_solution_get_num_vars", self._h)
+
+    def _wrap_var(self, h):
+        if not h:
+            self._lib.check()
+            raise RuntimeError("YASK error: var not found")
+        key = int(h)
+        if key not in self._vars:
+            self._vars[key] = yk_var(self._lib, h, self)
+        return self._vars[key]
+
+    def get_var(self, name):
+        h = self._lib.c.yk_solution_get_var(self._h, _b(name))
+        self._lib.check()
+        return self._wrap_var(h)
+
+    def get_vars(self):
+        return [self._wrap_var(self._lib.call("yk_solution_get_var_by_index", self._h, i)) for i in range(self.get_num_vars())]
+
+    def prepare_solution(self): self._lib.call_rc("yk_solution_prepare", self._h)
+
+    def run_solution(self, first_step_index, last_step_index=None):
+        if last_step_index is None:
+            last_step_index = first_step_index
+        self._lib.call_rc("yk_solution_run", self._h, int(first_step_index), int(last_step_index))
+
+    def end_solution(self): self._lib.call_rc("yk_solution_end", self._h)
+    def exchange_halos(self): self._lib.call_rc("yk_solution_exchange_halos", self._h)
+    def copy_vars_to_device(self): self._lib.call_rc("yk_solution_copy_vars_to_device", self._h)
+    def copy_vars_from_device(self): self._lib.call_rc("yk_solution_copy_vars_from_device", self._h)
+
+    def get_stats(self):
+        st = _capi.YkStats()
+        self._lib.call_rc("yk_solution_get_stats", self._h, C.byref(st))
+        return yk_stats(st)
+
+    def reset_auto_tuner(self, enable, verbose=False): self._lib.call_rc("yk_solution_reset_auto_tuner", self._h, int(enable), int(verbose))
+    def is_auto_tuner_enabled(self): return bool(self._lib.call("yk_solution_is_auto_tuner_enabled", self._h))
+    def run_auto_tuner_now(self, verbose=True): self._lib.call_rc("yk_solution_run_auto_tuner_now", self._h, int(verbose))
+
+    def new_var(self, name, dims):
+        arr = (C.c_char_p * len(dims))(*[_b(d) for d in dims])
+        h = self._lib.c.yk_solution_new_var(self._h, _b(name), len(dims), arr)
+        self._lib.check()
+        return self._wrap_var(h)
+
+    def new_fixed_size_var(self, name, dims, dim_sizes):
+        arr = (C.c_char_p * len(dims))(*[_b(d) for d in dims])
+        sz = (idx_t * len(dim_sizes))(*[int(s) for s in dim_sizes])
+        h = self._lib.c.yk_solution_new_fixed_size_var(self._h, _b(name), len(dims), arr, sz)
+        self._lib.check()
+        return self._wrap_var(h)
+
+    # ---- extensions beyond the reference API
+    def compare_data(self, ref, epsilon=1e-3):
+        """Number of in-domain mismatches vs `ref` (StencilContext::compare_data, context.cpp:1529-1547)."""
+        return self._lib.call("yk_solution_compare_data", self._h, ref._h, float(epsilon))
+    def set_streams(self, compute_stream, comm_stream):
+        self._lib.call_rc("yk_solution_set_streams", self._h, C.c_void_p(compute_stream), C.c_void_p(comm_stream))
+    def get_kernel_variant(self, part=0): return self._lib.call("yk_solution_get_kernel_variant", self._h, part).decode()
+    def get_kernel_variant_names(self, part=0):
+        n = self._lib.call("yk_solution_get_num_kernel_variants", self._h, part)
+        return [self._lib.call("yk_solution_get_kernel_variant_name", self._h, part, i).decode() for i in range(n)]
+    def time_part(self, part=0, variant=-1, xchunk=0, t=0, reps=1):
+        """Average HIP-event duration (ms) of `reps` launches of one stencil part."""
+        ms = C.c_float(0)
+        self._lib.call_rc("yk_solution_time_part", self._h, int(part), int(variant), int(xchunk), int(t), int(reps), C.byref(ms))
+        return float(ms.value)
+
+
+for _n in ["rank_domain_size", "overall_domain_size", "block_size", "num_ranks", "rank_index"]:
+    setattr(yk_solution, "get_" + _n, _dim_getter("yk_solution_get_" + _n))
+    setattr(yk_solution, "set_" + _n, _dim_setter("yk_solution_set_" + _n))
+for _n in ["first_rank_domain_index", "last_rank_domain_index"]:
+    setattr(yk_solution, "get_" + _n, _dim_getter("yk_solution_get_" + _n))
+
+
+class yk_env:
+    """yk_env (include/yask_kernel_api.hpp:167-295)."""
+    _trace = False
+
+    def __init__(self, lib, h):
+        self._lib, self._h = lib, h
+        self._keep = []     # keep ctypes callbacks alive
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.c.yk_free_env(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def get_num_ranks(self): return self._lib.call("yk_env_get_num_ranks", self._h)
+    def get_rank_index(self): return self._lib.call("yk_env_get_rank_index", self._h)
+    def global_barrier(self): self._lib.call_rc("yk_env_global_barrier", self._h)
+    def sum_over_ranks(self, v): return self._lib.call("yk_env_sum_over_ranks", self._h, int(v))
+    def finalize(self): pass
+    def exit(self, code): os._exit(code)
+    @staticmethod
+    def set_trace_enabled(enable): yk_env._trace = bool(enable)
+    @staticmethod
+    def is_trace_enabled(): return yk_env._trace
+    @staticmethod
+    def disable_debug_output(): pass
+
+    # ---- multi-GPU set-up (one process per GPU)
+    def set_ranks(self, rank, num_ranks): self._lib.call_rc("yk_env_set_ranks", self._h, int(rank), int(num_ranks))
+
+    def set_transport(self, start, wait, allreduce):
+        """Install Python callables as halo transport (see yask_amd.dist for torch.distributed ones)."""
+        s, w, a = _capi.EXCHANGE_FN(start), _capi.EXCHANGE_FN(wait), _capi.ALLREDUCE_FN(allreduce)
+        self._keep += [s, w, a]
+        self._lib.call_rc("yk_env_set_transport", self._h, s, w, a, None)
+
+    def init_rccl(self, unique_id: bytes, rank, num_ranks):
+        buf = C.create_string_buffer(unique_id, 128)
+        self._lib.call_rc("yk_env_init_rccl", self._h, buf, int(rank), int(num_ranks))
+
+    def rccl_get_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self._lib.call_rc("yk_rccl_get_unique_id", buf)
+        return buf.raw
+
+
+class yk_factory:
+    """yk_factory (include/yask_kernel_api.hpp:82-161). The reference builds one Python module per
+    stencil; here the stencil is chosen at construction (default: $YASK_STENCIL or 'iso3dfd')."""
+
+    def __init__(self, stencil=None):
+        self.stencil = stencil or os.environ.get("YASK_STENCIL", "iso3dfd")
+        self._lib = _Lib(self.stencil)
+
+    def get_version_string(self): return self._lib.call("yk_get_version_string").decode()
+
+    def new_env(self):
+        h = self._lib.c.yk_new_env()
+        self._lib.check()
+        if not h:
+            raise RuntimeError("YASK error: cannot create env")
+        return yk_env(self._lib, h)
+
+    def new_solution(self, env, source=None):
+        if source is None:
+            h = self._lib.c.yk_new_solution(env._h)
+        else:
+            h = self._lib.c.yk_new_solution_from(env._h, source._h)
+        self._lib.check()
+        if not h:
+            raise RuntimeError("YASK error: cannot create solution")
+        return yk_solution(self._lib, h, env)
