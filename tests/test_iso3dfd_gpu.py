@@ -42,7 +42,8 @@ def variants():
     fac = yk_factory("iso3dfd")
     env = fac.new_env()
     s = fac.new_solution(env)
-    return s.get_kernel_variant_names(0)
+    # 'abl*' variants are deliberately-wrong profiling ablations
+    return [n for n in s.get_kernel_variant_names(0) if not n.startswith('abl')]
 
 
 def test_every_kernel_variant_matches_oracle(gpu):

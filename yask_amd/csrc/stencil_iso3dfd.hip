@@ -26,8 +26,17 @@ const SolnImpl& ykh_solution_impl() {
         p.variants.push_back(star_variant<part_1, 32, 8, 2, ROT_MOVE>());
         p.variants.push_back(star_variant<part_1, 32, 8, 2, ROT_UNROLL>());
         p.variants.push_back(star_variant<part_1, 16, 16, 1, ROT_MOVE>());
-        p.variants.push_back(star_variant<part_1, 64, 16, 1, ROT_MOVE>());
-        p.default_variant = 1;
+        p.variants.push_back(star_variant<part_1, 32, 16, 2, ROT_MOVE>());
+        p.variants.push_back(star_variant<part_1, 32, 16, 2, ROT_UNROLL>());
+        p.variants.push_back(star_variant<part_1, 64, 8, 2, ROT_MOVE>());
+        p.variants.push_back(star_variant<part_1, 64, 8, 2, ROT_UNROLL>());
+        p.variants.push_back(star_variant<part_1, 64, 4, 2, ROT_UNROLL>());
+        p.variants.push_back(star_variant<part_1, 16, 32, 1, ROT_UNROLL>());
+        p.variants.push_back(star_variant<part_1, 32, 16, 1, ROT_UNROLL, 1>());
+        p.variants.push_back(star_variant<part_1, 32, 16, 1, ROT_UNROLL, 2>());
+        p.variants.push_back(star_variant<part_1, 32, 16, 1, ROT_UNROLL, 4>());
+        p.variants.push_back(star_variant<part_1, 32, 16, 1, ROT_UNROLL, 7>());
+        p.default_variant = 6;   // star25d_z128_y16_r1_u
         s.parts.push_back(p);
         return s;
     }();

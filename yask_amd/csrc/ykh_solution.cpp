@@ -670,6 +670,7 @@ void Solution::run_auto_tuner_now() {
         idx_t best_xc = part_xchunk[p];
         for (size_t k = 0; k < pi.variants.size(); k++) {
             if (!pi.variants[k].star && pi.variants.size() > 1 && !force_scalar) continue;   // naive only as last resort
+            if (std::strncmp(pi.variants[k].name, "abl", 3) == 0) continue;                   // profiling ablations
             std::vector<idx_t> chunks = {0};
             if (pi.variants[k].star) { chunks.push_back(rb.hi[0] - rb.lo[0]); chunks.push_back(256); chunks.push_back(128); }
             for (idx_t xc : chunks) {

@@ -14,17 +14,17 @@ void launch_naive(const PartArgs& a, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL((naive_kernel<P>), grid, dim3(256), 0, s, a);
 }
 
-template <class P, int TZL, int TYL, int RY, int ROT>
+template <class P, int TZL, int TYL, int RY, int ROT, int ABL = 0>
 void launch_star(const PartArgs& a, dim3 grid, hipStream_t s) {
     typedef Star25dCfg<P, TZL, TYL, RY, ROT> C;
     static bool attr_set = false;
     if (!attr_set) {
         // allow more than the default 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&star25d_kernel<P, TZL, TYL, RY, ROT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&star25d_kernel<P, TZL, TYL, RY, ROT, ABL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((star25d_kernel<P, TZL, TYL, RY, ROT>), grid, dim3(C::NT), C::lds_bytes, s, a);
+    hipLaunchKernelGGL((star25d_kernel<P, TZL, TYL, RY, ROT, ABL>), grid, dim3(C::NT), C::lds_bytes, s, a);
 }
 
 template <class P>
@@ -32,12 +32,15 @@ KernelVariant naive_variant() {
     return KernelVariant{"naive", false, 64, 4, 0, 256, &launch_naive<P>};
 }
 
-template <class P, int TZL, int TYL, int RY, int ROT>
+// ABL != 0 variants compute WRONG results on purpose (profiling ablations); their names start with
+// "abl" and neither the default selection nor the auto-tuner ever picks them.
+template <class P, int TZL, int TYL, int RY, int ROT, int ABL = 0>
 KernelVariant star_variant() {
     typedef Star25dCfg<P, TZL, TYL, RY, ROT> C;
-    static const std::string name = "star25d_z" + std::to_string(C::TZ) + "_y" + std::to_string(C::TY) + "_r" +
+    static const std::string name = std::string(ABL ? "abl" + std::to_string(ABL) + "_" : "") + "star25d_z" +
+                                    std::to_string(C::TZ) + "_y" + std::to_string(C::TY) + "_r" +
                                     std::to_string(RY) + (ROT == ROT_UNROLL ? "_u" : "_m");
-    return KernelVariant{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_star<P, TZL, TYL, RY, ROT>};
+    return KernelVariant{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_star<P, TZL, TYL, RY, ROT, ABL>};
 }
 
 }  // namespace ykh
