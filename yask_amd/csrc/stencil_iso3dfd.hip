@@ -1,10 +1,16 @@
-// stencil_iso3dfd.hip -- kernel instantiations for solution 'iso3dfd' (16th-order isotropic 3-D
+// stencil_iso3dfd.hip -- kernel registry of solution 'iso3dfd' (16th-order isotropic 3-D
 // finite-difference wave propagation; DSL: src/stencils/Iso3dfdStencil.cpp of the reference).
-// Links with the generic runtime into libyask_kernel.iso3dfd.cdna4_hip.so.
+// The tile-shape instantiations live in stencil_iso3dfd_k*.hip; everything links with the generic
+// runtime into libyask_kernel.iso3dfd.cdna4_hip.so.
 #include "gen/iso3dfd_cdna4_hip.hpp"
 #include "ykh_stencil_tu.hpp"
 
 namespace ykh {
+void iso3dfd_variants_k1(PartImpl&);   // star25d (gather) shapes
+void iso3dfd_variants_k2(PartImpl&);   // starlin (gather past / scatter future) shapes
+void iso3dfd_variants_k3(PartImpl&);
+void iso3dfd_variants_k4(PartImpl&);
+void iso3dfd_variants_k5(PartImpl&);   // profiling ablations ("abl*": wrong results on purpose)
 
 const SolnImpl& ykh_solution_impl() {
     using namespace ykh_gen_iso3dfd;
@@ -14,29 +20,12 @@ const SolnImpl& ykh_solution_impl() {
         PartImpl p;
         p.meta = &parts[0];
         p.variants.push_back(naive_variant<part_1>());
-        // <lanes along z (x4 floats), thread rows, rows per thread, queue rotation>
-        p.variants.push_back(star_variant<part_1, 32, 8, 1, ROT_MOVE>());
-        p.variants.push_back(star_variant<part_1, 32, 8, 1, ROT_UNROLL>());
-        p.variants.push_back(star_variant<part_1, 64, 4, 1, ROT_MOVE>());
-        p.variants.push_back(star_variant<part_1, 64, 4, 1, ROT_UNROLL>());
-        p.variants.push_back(star_variant<part_1, 32, 16, 1, ROT_MOVE>());
-        p.variants.push_back(star_variant<part_1, 32, 16, 1, ROT_UNROLL>());
-        p.variants.push_back(star_variant<part_1, 64, 8, 1, ROT_MOVE>());
-        p.variants.push_back(star_variant<part_1, 64, 8, 1, ROT_UNROLL>());
-        p.variants.push_back(star_variant<part_1, 32, 8, 2, ROT_MOVE>());
-        p.variants.push_back(star_variant<part_1, 32, 8, 2, ROT_UNROLL>());
-        p.variants.push_back(star_variant<part_1, 16, 16, 1, ROT_MOVE>());
-        p.variants.push_back(star_variant<part_1, 32, 16, 2, ROT_MOVE>());
-        p.variants.push_back(star_variant<part_1, 32, 16, 2, ROT_UNROLL>());
-        p.variants.push_back(star_variant<part_1, 64, 8, 2, ROT_MOVE>());
-        p.variants.push_back(star_variant<part_1, 64, 8, 2, ROT_UNROLL>());
-        p.variants.push_back(star_variant<part_1, 64, 4, 2, ROT_UNROLL>());
-        p.variants.push_back(star_variant<part_1, 16, 32, 1, ROT_UNROLL>());
-        p.variants.push_back(star_variant<part_1, 32, 16, 1, ROT_UNROLL, 1>());
-        p.variants.push_back(star_variant<part_1, 32, 16, 1, ROT_UNROLL, 2>());
-        p.variants.push_back(star_variant<part_1, 32, 16, 1, ROT_UNROLL, 4>());
-        p.variants.push_back(star_variant<part_1, 32, 16, 1, ROT_UNROLL, 7>());
-        p.default_variant = 6;   // star25d_z128_y16_r1_u
+        iso3dfd_variants_k1(p);
+        iso3dfd_variants_k2(p);
+        iso3dfd_variants_k3(p);
+        iso3dfd_variants_k4(p);
+        iso3dfd_variants_k5(p);
+        p.set_default("starlin_v4_z128_y32_r2_m_nt_w2_c4");
         s.parts.push_back(p);
         return s;
     }();

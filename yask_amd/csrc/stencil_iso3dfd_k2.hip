@@ -1,0 +1,14 @@
+// stencil_iso3dfd_k2.hip -- kernel instantiations for solution 'iso3dfd', group 2 (split over several
+// translation units so that hipcc compiles the tile shapes in parallel).
+#include "gen/iso3dfd_cdna4_hip.hpp"
+#include "ykh_stencil_tu.hpp"
+
+namespace ykh {
+using namespace ykh_gen_iso3dfd;
+void iso3dfd_variants_k2(PartImpl& p) {
+    p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 1, 2, 4, 0>());
+    p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 0, 2, 4, 0>());
+    p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 1, ROT_MOVE, 1, 2, 4, 0>());
+    p.variants.push_back(starlin_variant<part_1, 4, 32, 8, 1, ROT_MOVE, 1, 3, 4, 0>());
+}
+}  // namespace ykh

@@ -46,6 +46,13 @@ struct ReadOff {
     signed char dx, dy, dz;   // offsets by domain_idx (x = domain_idx 0)
 };
 
+// One term of a part's *linear star form* (see ykh_starlin.hpp): coefficient c multiplies the read of
+// the star group at offset (dx,dy,dz); at most one of the offsets is non-zero.
+struct LinTerm {
+    signed char dx, dy, dz;
+    double c;
+};
+
 struct PartMeta {
     const char* name;
     int n_groups;

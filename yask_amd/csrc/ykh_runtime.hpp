@@ -45,11 +45,17 @@ struct KernelVariant {
     size_t lds_bytes;
     int threads;
     void (*launch)(const PartArgs& a, dim3 grid, hipStream_t s);
+    int vz = 0;            // elements per thread along z (0: one 16-byte vector)
 };
 struct PartImpl {
     const PartMeta* meta;
     std::vector<KernelVariant> variants;   // variants[0] is the always-legal naive kernel
-    int default_variant;
+    int default_variant = 0;
+    void set_default(const char* name) {
+        for (size_t i = 0; i < variants.size(); i++)
+            if (std::string(variants[i].name) == name) { default_variant = (int)i; return; }
+        throw std::runtime_error(std::string("no kernel variant named ") + name);
+    }
 };
 struct SolnImpl {
     const SolnMeta* meta;
@@ -77,6 +83,7 @@ class Env {
 public:
     int rank = 0, nranks = 1;
     int device = 0;
+    int num_cus = 256;                      // compute units of the device (MI355X: 256)
     ykh_exchange_fn exch_start = nullptr;   // begin moving all msgs (async on `stream`)
     ykh_exchange_fn exch_wait = nullptr;    // make `stream` wait until they have landed
     ykh_allreduce_fn allreduce = nullptr;

@@ -40,6 +40,8 @@ Env::Env() {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         YKH_THROW("no HIP device is visible: the cdna4_hip kernel library needs an AMD GPU (there is no CPU fallback)");
     (void)hipGetDevice(&device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) num_cus = prop.multiProcessorCount;
 }
 void Env::set_ranks(int r, int n) {
     if (n < 1 || r < 0 || r >= n) YKH_THROW("invalid rank " + std::to_string(r) + " of " + std::to_string(n));
@@ -524,7 +526,7 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
     PartArgs a;
     fill_part_args(part, t, box, a);
     if (kv.star) {
-        const int vz = 16 / elem_bytes();
+        const int vz = kv.vz > 0 ? kv.vz : 16 / elem_bytes();
         idx_t zt0 = box.lo[2] & ~(idx_t)(vz - 1);
         a.ntz = (int)ceil_div(box.hi[2] - zt0, kv.tz);
         a.nty = (int)ceil_div(box.hi[1] - box.lo[1], kv.ty);
@@ -533,7 +535,7 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
         if (xc <= 0) {
             // default: march the whole box unless that leaves the chip short of workgroups
             idx_t tiles = (idx_t)a.ntz * a.nty;
-            idx_t want = 1024;
+            idx_t want = env->num_cus;   // one block per CU at least; whole-x marches otherwise (fewest halo planes)
             idx_t nchunks = std::max<idx_t>(1, std::min<idx_t>(ceil_div(want, tiles), ceil_div(nx, 64)));
             xc = ceil_div(nx, nchunks);
         }

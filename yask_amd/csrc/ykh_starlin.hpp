@@ -1,0 +1,397 @@
+// ykh_starlin.hpp -- second-generation 2.5-D kernel for parts in *linear star form*.
+//
+// A part is in linear star form when its single equation can be written as
+//     out = F( centre-only operands , L ),   L = sum_i c_i * S(x+dx_i, y+dy_i, z+dz_i)
+// with S one (var, step) access group ("star group"), every offset axis-aligned and every c_i a
+// compile-time constant.  iso3dfd (src/stencils/Iso3dfdStencil.cpp:63-137: L = the 49-point
+// Laplacian of p(t), F = 2p(t) - p(t-1) + v*L) and the AxisStencil family (`3axis`,
+// src/stencils/SimpleStencils.cpp:61-103) have it; the `cdna4_hip` compiler target detects the form
+// and emits `lin[]` + `eval_lin()` next to the general `eval()`.
+//
+// Why a second kernel shape.  star25d (ykh_device.hpp) gathers all x-neighbours from a register queue
+// of XL+XH+1 planes, so a plane's (y,z) halo is fetched XH planes *after* the neighbouring tiles
+// streamed the same lines as their interior; at r=8 that reuse distance (8 planes x 3 streams x
+// ~0.5 MB per XCD) exceeds the 4 MiB L2 and every halo line is fetched twice over the fabric
+// (rocprof: FETCH 1.39x the algorithmic read bytes, profiles/r01a_star25d_v1).  Here the x direction
+// is split into a *gathered past* and a *scattered future*:
+//     when plane X arrives (interior + halos, all loaded at the same time by all tiles)
+//       acc[X]    = sum_{dx<=0} c(dx)*S(X+dx) [register queue of the past XL planes]
+//                 + sum_{dy,dz} c*S(X, y+dy, z+dz)   [LDS slab of plane X]
+//       acc[X-k] += c(+k) * S(X)   for k = 1..XH      [partial sums held in registers]
+//       out[X-XH] = F(operands(X-XH), acc[X-XH])      [complete now]
+// The register budget is the same as star25d's (XL+1 queue planes + XH+1 partial sums vs XL+XH+1
+// planes) but each plane of S is touched once, at one time, by every tile that needs it -> halo lines
+// hit in L2 while the neighbour's interior load is still resident.  Centre-only operands and the
+// output are streamed with non-temporal hints so that they do not evict S from L2.
+// The summation order differs from the reference's expression order (rounding-level differences only;
+// parity tolerance stated in tests/).
+#pragma once
+#include "ykh_device.hpp"
+
+namespace ykh {
+
+template <class P>
+constexpr double lin_coef(int dx, int dy, int dz) {
+    double s = 0;
+    for (int i = 0; i < P::n_lin; i++)
+        if (P::lin[i].dx == dx && P::lin[i].dy == dy && P::lin[i].dz == dz) s += P::lin[i].c;
+    return s;
+}
+
+template <class P>
+constexpr StarRange lin_range() {
+    StarRange r = {0, 0, 0, 0, 0, 0, false, P::n_lin > 0, false};
+    for (int i = 0; i < P::n_lin; i++) {
+        int dx = P::lin[i].dx, dy = P::lin[i].dy, dz = P::lin[i].dz;
+        int nz = (dx != 0) + (dy != 0) + (dz != 0);
+        if (nz == 0) r.center = true;
+        if (nz > 1) { r.mixed = true; continue; }
+        if (dx < r.xlo) r.xlo = dx;
+        if (dx > r.xhi) r.xhi = dx;
+        if (dy < r.ylo) r.ylo = dy;
+        if (dy > r.yhi) r.yhi = dy;
+        if (dz < r.zlo) r.zlo = dz;
+        if (dz > r.zhi) r.zhi = dz;
+    }
+    return r;
+}
+
+constexpr int ce_gcd(int a, int b) { return b == 0 ? a : ce_gcd(b, a % b); }
+// physical slot of logical queue entry i at rotation phase ph (queue of N entries)
+template <int N>
+constexpr int rot(int ph, int i) { return ((ph + i) % N + N) % N; }
+
+// z-vector of N elements (N*sizeof(T) <= 16 bytes)
+template <typename T, int N> struct vecn { typedef T type __attribute__((ext_vector_type(N))); };
+
+// elements S..S+N-1 of the concatenation (lo, hi)
+template <typename T, int N, int S>
+__device__ __forceinline__ typename vecn<T, N>::type zshiftn(typename vecn<T, N>::type lo, typename vecn<T, N>::type hi) {
+    static_assert(N == 2 || N == 4, "z-vector of 2 or 4 elements");
+    if constexpr (S == 0) return lo;
+    else if constexpr (N == 4) {
+        if constexpr (S == 1) return __builtin_shufflevector(lo, hi, 1, 2, 3, 4);
+        else if constexpr (S == 2) return __builtin_shufflevector(lo, hi, 2, 3, 4, 5);
+        else return __builtin_shufflevector(lo, hi, 3, 4, 5, 6);
+    } else return __builtin_shufflevector(lo, hi, 1, 2);
+}
+
+// VZ_ elements along z per thread (4 -> 16-byte accesses for fp32; 2 halves the per-thread state so
+// that twice as many waves fit the register file); TZL_ lanes along z, TYL_ thread rows, RY_ rows
+// per thread; CH_ = LDS reads in flight per batch.
+template <class P, int VZ_, int TZL_, int TYL_, int RY_, int ROT_, int CH_>
+struct StarLinCfg {
+    typedef typename P::real_t T;
+    static constexpr int VZ = VZ_;
+    typedef typename vecn<T, VZ_>::type V;
+    static constexpr int TZL = TZL_, TYL = TYL_, RY = RY_, ROT = ROT_, CH = CH_;
+    static constexpr int NT = TZL * TYL;
+    static constexpr int SG = P::lin_group;
+    static constexpr StarRange R = lin_range<P>();
+    static constexpr int XL = -R.xlo, XH = R.xhi, YL = -R.ylo, YH = R.yhi, ZL = -R.zlo, ZH = R.zhi;
+    static constexpr int NP = (XL > XH ? XL : XH) + 1;   // queue of S planes X-NP+1 .. X
+    static constexpr int NA = XH + 1;                    // partial sums of outputs X-XH .. X
+    static constexpr int PERIOD = NP / ce_gcd(NP, NA) * NA;
+    // LDS slab ring: with the unrolled loop the slab of a plane is a compile-time function of the
+    // rotation phase (no per-plane address arithmetic): 2 slabs if the unroll count is even, 3 if it
+    // is a multiple of 3, otherwise the loop is unrolled 2*PERIOD times.
+    static constexpr int NS = (ROT_ == ROT_UNROLL && PERIOD % 2 != 0 && PERIOD % 3 == 0) ? 3 : 2;
+    static constexpr int UNR = (PERIOD % NS == 0) ? PERIOD : 2 * PERIOD;
+    static constexpr int ZLV = (ZL + VZ - 1) / VZ, ZHV = (ZH + VZ - 1) / VZ;
+    static constexpr int TZ = TZL * VZ, TY = TYL * RY;
+    static constexpr int LP = TZ + (ZLV + ZHV) * VZ;
+    static constexpr int LROWS = TY + YL + YH;
+    static constexpr int NHY = (YL + YH) * TZL;
+    static constexpr int NHZ = TY * (ZLV + ZHV);
+    static constexpr int NH = NHY + NHZ;
+    static constexpr int NHT = (NH + NT - 1) / NT;
+    static constexpr int NW = ZLV + 1 + ZHV;
+    static constexpr size_t lds_bytes = sizeof(T) * NS * LROWS * LP;
+    // y neighbours with a non-zero coefficient, in offset order
+    static constexpr int count_y() { int n = 0; for (int dy = -YL; dy <= YH; dy++) if (dy != 0 && lin_coef<P>(0, dy, 0) != 0.0) n++; return n; }
+    static constexpr int NY = count_y();
+    static constexpr int y_off(int i) { int n = 0; for (int dy = -YL; dy <= YH; dy++) if (dy != 0 && lin_coef<P>(0, dy, 0) != 0.0) { if (n == i) return dy; n++; } return 0; }
+};
+
+// accessor handed to P::eval_lin(): centre reads only
+template <class C>
+struct LinAcc {
+    typedef typename C::T T;
+    typedef typename C::V V;
+    const V& scen;                    // star group at the output point
+    const V (&cen)[MAX_GROUPS];       // other groups at the output point
+    V (&out)[MAX_GROUPS];
+    template <int G, int DX, int DY, int DZ>
+    __device__ __forceinline__ V rd() const {
+        static_assert(DX == 0 && DY == 0 && DZ == 0, "eval_lin: only centre reads are allowed outside the linear form");
+        if constexpr (G == C::SG) return scen;
+        else return cen[G];
+    }
+    template <int G>
+    __device__ __forceinline__ void wr(V v) { out[G] = v; }
+};
+
+template <class V, typename T> __device__ __forceinline__ V ldv(const T* p) { return *reinterpret_cast<const V*>(p); }
+template <class V, typename T> __device__ __forceinline__ void stv(T* p, V v) { *reinterpret_cast<V*>(p) = v; }
+template <class V, typename T> __device__ __forceinline__ V ldv_nt(const T* p) { return __builtin_nontemporal_load(reinterpret_cast<const V*>(p)); }
+template <class V, typename T> __device__ __forceinline__ void stv_nt(T* p, V v) { __builtin_nontemporal_store(v, reinterpret_cast<V*>(p)); }
+
+// NTH : 1 = non-temporal loads of centre-only operands and non-temporal stores.
+// MINW: minimum resident waves per SIMD the register allocation must allow (k blocks of T threads per
+//       CU <=> k*T/256), MI355X_MICROARCH.md "Register files".
+// ABL (profiling only): 1 = no halo loads, 2 = no centre-operand loads, 4 = no stores.
+template <class P, int VZ, int TZL, int TYL, int RY, int ROT, int NTH, int MINW, int CH, int ABL = 0>
+__global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs a) {
+    typedef StarLinCfg<P, VZ, TZL, TYL, RY, ROT, CH> C;
+    typedef typename C::T T;
+    typedef typename C::V V;
+    constexpr int NP = C::NP, NA = C::NA, XL = C::XL, XH = C::XH, YL = C::YL;
+    constexpr int ZLV = C::ZLV, ZHV = C::ZHV, LP = C::LP, NT = C::NT, NHT = C::NHT, NY = C::NY;
+    constexpr int SG = C::SG, NG = P::n_groups;
+    static_assert(!C::R.mixed, "linear form has a mixed-offset term");
+    static_assert(NG <= MAX_GROUPS, "too many access groups");
+    static_assert(VZ * sizeof(T) <= 16, "z-vector wider than 16 bytes");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char ykh_smem[];
+    T* slab = reinterpret_cast<T*>(ykh_smem);
+
+    // XCD-aware tile assignment (see star25d_kernel): each XCD owns a contiguous range of (y,z) tiles.
+    const int ntiles = a.ntz * a.nty * a.nxc;
+    int bid = blockIdx.x;
+    if ((ntiles & 7) == 0) bid = (bid & 7) * (ntiles >> 3) + (bid >> 3);
+    const int tz_i = bid % a.ntz;
+    const int ty_i = (bid / a.ntz) % a.nty;
+    const int xc_i = bid / (a.ntz * a.nty);
+
+    const int tid = threadIdx.x;
+    const int lz = tid % TZL, ly = tid / TZL;
+    const int zt0 = (a.z0 & ~(VZ - 1)) + tz_i * C::TZ;
+    const int yt0 = a.y0 + ty_i * C::TY;
+    const int xs = a.x0 + xc_i * a.xchunk;
+    const int xe = (xs + a.xchunk < a.x1) ? xs + a.xchunk : a.x1;
+    if (xs >= xe) return;
+    const int xlast = xe + XH;       // planes xs .. xlast-1 arrive
+
+    const int myz = zt0 + lz * VZ;
+    const int zc = clampi(myz, a.az0, a.az1 - VZ);
+    const T* __restrict__ sp = (const T*)a.ptr[SG];
+
+    // plane-relative element offsets (int: a plane has < 2^31 elements)
+    int roff[RY];
+    static_for<RY>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        int y = clampi(yt0 + ly * RY + j, a.ay0, a.ay1 - 1);
+        roff[j] = y * (int)a.sy + zc;
+    });
+    int hoff[NHT > 0 ? NHT : 1];
+    int hlds[NHT > 0 ? NHT : 1];
+    static_for<NHT>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int ZV2 = (ZLV + ZHV > 0) ? ZLV + ZHV : 1;
+        int h = tid + k * NT;
+        int row, zv;
+        if (h < C::NHY) {
+            int r = h / TZL;
+            row = r < YL ? r : r + C::TY;
+            zv = ZLV + h % TZL;
+        } else {
+            int hh = h - C::NHY;
+            int r = hh / ZV2, c = hh % ZV2;
+            row = YL + r;
+            zv = c < ZLV ? c : c + TZL;
+        }
+        if (h >= C::NH) { row = 0; zv = 0; }
+        int y = clampi(yt0 - YL + row, a.ay0, a.ay1 - 1);
+        int z = clampi(zt0 - ZLV * VZ + zv * VZ, a.az0, a.az1 - VZ);
+        hoff[k] = y * (int)a.sy + z;
+        hlds[k] = (h < C::NH) ? row * LP + zv * VZ : -1;
+    });
+
+    auto xplane = [&](int x) -> idx_t { return (idx_t)clampi(x, a.ax0, a.ax1 - 1) * a.sx; };
+
+    V pq[NP][RY];
+    V acc[NA][RY];
+    V nxt[RY];
+    V hreg[NHT > 0 ? NHT : 1];
+    V cen[NG][RY];     // centre-only operands of the next output plane (one set, refilled after use)
+
+    auto load_centres = [&](idx_t pc) {
+        static_for<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g != SG && analyze_group<P>(g).any) {
+                const T* gp = (const T*)a.ptr[g] + pc;
+                static_for<RY>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr (ABL & 2) cen[g][j] = V(1);
+                    else if constexpr (NTH) cen[g][j] = ldv_nt<V>(gp + roff[j]);
+                    else cen[g][j] = ldv<V>(gp + roff[j]);
+                });
+            }
+        });
+    };
+    auto load_plane = [&](int x) {
+        const T* pp = sp + xplane(x);
+        static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; nxt[j] = ldv<V>(pp + roff[j]); });
+        static_for<NHT>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (ABL & 1) hreg[k] = V(0); else hreg[k] = ldv<V>(pp + hoff[k]);
+        });
+    };
+
+    // ---- prologue: the past planes xs-NP+1 .. xs-1 (tile interior only), zeroed partial sums,
+    // and the first arriving plane xs with its halos.
+    static_for<NP - 1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const T* pp = sp + xplane(xs - (NP - 1) + i);
+        static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; pq[i][j] = ldv<V>(pp + roff[j]); });
+    });
+    static_for<NA>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; acc[i][j] = V(0); });
+    });
+    load_plane(xs);
+    if constexpr (XH == 0) load_centres(xplane(xs));
+
+    // One arriving plane. PH renames the queue slots when the loop is unrolled PERIOD times.
+    auto plane = [&](int xin, auto ph_tag) {
+        constexpr int PH = decltype(ph_tag)::value;
+        constexpr int qn = rot<NP>(PH, NP - 1), an = rot<NA>(PH, NA - 1);
+        constexpr int qo = rot<NP>(PH, NP - 1 - XH), ao = rot<NA>(PH, 0);
+        T* sb;
+        if constexpr (ROT == ROT_UNROLL) sb = slab + (PH % C::NS) * (C::LROWS * LP);
+        else sb = slab + ((xin - xs) & 1) * (C::LROWS * LP);
+        const int xo = xin - XH;
+        static_for<RY>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            pq[qn][j] = nxt[j];
+            stv<V>(sb + (YL + ly * RY + j) * LP + (ZLV + lz) * VZ, nxt[j]);
+        });
+        static_for<NHT>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (hlds[k] >= 0) stv<V>(sb + hlds[k], hreg[k]);
+        });
+        // prefetch the next arriving plane (registers of nxt/hreg are free again)
+        load_plane(xin + 1);
+        __syncthreads();
+
+        const T* colp = sb + (ZLV + lz) * VZ;
+        static_for<RY>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const V c = pq[qn][j];
+            const T* rowc = colp + (YL + ly * RY + j) * LP;     // own element in the slab
+            // ---- new partial sum for output plane xin: centre and past x from registers ...
+            constexpr T c000 = T(lin_coef<P>(0, 0, 0));
+            V s = c * c000;
+            static_for<XL>([&](auto kc) {
+                constexpr int k = decltype(kc)::value + 1;
+                constexpr T ck = T(lin_coef<P>(-k, 0, 0));
+                constexpr int qi = rot<NP>(PH, NP - 1 - k);
+                s += pq[qi][j] * ck;
+            });
+            // ... y neighbours from the slab and z neighbours from a window of the own row, in batches
+            // of CH reads, double-buffered: while batch b is summed, batch b+1 is in flight.  The
+            // empty asm pins the partial sum (and, through its memory clobber, the later reads) in
+            // program order; unconstrained, hipcc issues all NY+NW reads first and needs VZ*(NY+NW)
+            // more VGPRs, which costs a wave per SIMD.
+            constexpr int NZW = (C::ZL + C::ZH > 0) ? C::NW - 1 : 0;       // window reads (own vector comes from c)
+            constexpr int NRD = NY + NZW;                                  // LDS reads per row
+            constexpr int NB = (NRD + CH - 1) / CH;
+            V t[NB > 0 ? NB : 1][CH];
+            V zw[C::NW];
+            zw[ZLV] = c;
+            auto issue = [&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                static_for<CH>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, r = b * CH + i;
+                    if constexpr (r < NY) {
+                        constexpr int dy = C::y_off(r);
+                        t[b][i] = ldv<V>(rowc + dy * LP);
+                    }
+                    else if constexpr (r < NRD) {
+                        constexpr int w = (r - NY) < ZLV ? (r - NY) : (r - NY) + 1;
+                        zw[w] = ldv<V>(rowc + (w - ZLV) * VZ);
+                    }
+                });
+            };
+            if constexpr (NB > 0) issue(std::integral_constant<int, 0>{});
+            static_for<NB>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                if constexpr (b + 1 < NB) issue(std::integral_constant<int, b + 1>{});
+                static_for<CH>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, r = b * CH + i;
+                    if constexpr (r < NY) {
+                        constexpr int dy = C::y_off(r);
+                        constexpr T ck = T(lin_coef<P>(0, dy, 0));
+                        s += t[b][i] * ck;
+                    }
+                });
+                asm volatile("" : "+v"(s) : : "memory");
+            });
+            if constexpr (NZW > 0) {
+                static_for<C::ZL + C::ZH + 1>([&](auto dc) {
+                    constexpr int dz = decltype(dc)::value - C::ZL;
+                    if constexpr (dz != 0 && lin_coef<P>(0, 0, dz) != 0.0) {
+                        constexpr int e = ZLV * VZ + dz;
+                        constexpr T ck = T(lin_coef<P>(0, 0, dz));
+                        s += zshiftn<T, VZ, e % VZ>(zw[e / VZ], zw[(e / VZ + 1) < C::NW ? (e / VZ + 1) : e / VZ]) * ck;
+                    }
+                });
+            }
+            acc[an][j] = s;
+            // ---- this plane's contribution to the outputs still waiting for their future
+            static_for<XH>([&](auto kc) {
+                constexpr int k = decltype(kc)::value + 1;
+                constexpr T ck = T(lin_coef<P>(k, 0, 0));
+                constexpr int ai = rot<NA>(PH, NA - 1 - k);
+                acc[ai][j] += c * ck;
+            });
+            // ---- output plane xo = xin - XH is complete
+            V cj[MAX_GROUPS], out[MAX_GROUPS];
+            static_for<NG>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if constexpr (g != SG && analyze_group<P>(g).any) cj[g] = cen[g][j];
+            });
+            LinAcc<C> la{pq[qo][j], cj, out};
+            P::eval_lin(la, acc[ao][j]);
+            const int y = yt0 + ly * RY + j;
+            if (xo >= xs && xo < xe && y < a.y1 && myz < a.z1 && myz + VZ > a.z0) {
+                const idx_t o = (idx_t)xo * a.sx + (idx_t)y * a.sy + myz;
+                static_for<P::n_writes>([&](auto wc) {
+                    constexpr int g = P::writes[decltype(wc)::value];
+                    T* op = (T*)a.ptr[g] + o;
+                    if constexpr (ABL & 4) { if (out[g][0] == T(123.456)) op[0] = out[g][0]; }
+                    else if (myz >= a.z0 && myz + VZ <= a.z1) {
+                        if constexpr (NTH) stv_nt<V>(op, out[g]); else stv<V>(op, out[g]);
+                    } else
+                        static_for<VZ>([&](auto ec) {
+                            constexpr int e = decltype(ec)::value;
+                            if (myz + e >= a.z0 && myz + e < a.z1) op[e] = out[g][e];
+                        });
+                });
+            }
+        });
+        // operands of the next output plane: a whole plane of work hides their latency
+        if (xo + 1 >= xs && xo + 1 < xe) load_centres((idx_t)(xo + 1) * a.sx);
+    };
+
+    if constexpr (ROT == ROT_MOVE) {
+        for (int x = xs; x < xlast; x++) {
+            plane(x, std::integral_constant<int, 0>{});
+            static_for<NP - 1>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; pq[i][j] = pq[i + 1][j]; });
+            });
+            static_for<NA - 1>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; acc[i][j] = acc[i + 1][j]; });
+            });
+        }
+    } else {
+        // UNR planes per trip (queue rotation by renaming); the last trip may run past xlast-1:
+        // loads are clamped to the allocation and stores are predicated on xo < xe.
+        for (int x = xs; x < xlast; x += C::UNR)
+            static_for<C::UNR>([&](auto phc) { plane(x + decltype(phc)::value, phc); });
+    }
+}
+
+}  // namespace ykh

@@ -5,6 +5,7 @@
 #include <string>
 
 #include "ykh_device.hpp"
+#include "ykh_starlin.hpp"
 #include "ykh_runtime.hpp"
 
 namespace ykh {
@@ -41,6 +42,32 @@ KernelVariant star_variant() {
                                     std::to_string(C::TZ) + "_y" + std::to_string(C::TY) + "_r" +
                                     std::to_string(RY) + (ROT == ROT_UNROLL ? "_u" : "_m");
     return KernelVariant{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_star<P, TZL, TYL, RY, ROT, ABL>};
+}
+
+template <class P, int VZ, int TZL, int TYL, int RY, int ROT, int NTH, int MINW, int CH, int ABL = 0>
+void launch_starlin(const PartArgs& a, dim3 grid, hipStream_t s) {
+    typedef StarLinCfg<P, VZ, TZL, TYL, RY, ROT, CH> C;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&starlin_kernel<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((starlin_kernel<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL>), grid, dim3(C::NT), C::lds_bytes, s, a);
+}
+
+// Linear-star-form kernel (ykh_starlin.hpp); only for parts with P::has_lin.
+// Name: starlin_v<VZ>_z<tile z>_y<tile y>_r<rows/thread>_{u|m}[_nt]_w<min waves/SIMD>_c<LDS batch>
+template <class P, int VZ, int TZL, int TYL, int RY, int ROT, int NTH, int MINW, int CH, int ABL = 0>
+KernelVariant starlin_variant() {
+    typedef StarLinCfg<P, VZ, TZL, TYL, RY, ROT, CH> C;
+    static const std::string name = std::string(ABL ? "abl" + std::to_string(ABL) + "_" : "") + "starlin_v" + std::to_string(VZ) +
+                                    "_z" + std::to_string(C::TZ) + "_y" + std::to_string(C::TY) + "_r" +
+                                    std::to_string(RY) + (ROT == ROT_UNROLL ? "_u" : "_m") + (NTH ? "_nt" : "") + "_w" +
+                                    std::to_string(MINW) + "_c" + std::to_string(CH);
+    KernelVariant kv{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_starlin<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL>};
+    kv.vz = VZ;
+    return kv;
 }
 
 }  // namespace ykh
