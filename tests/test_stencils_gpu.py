@@ -1,0 +1,132 @@
+"""GPU parity of the other two hot-path stencils against the oracle
+and the golden outputs of the unmodified reference:
+  3axis  (AxisStencil r=4, fp64): stated tolerance rel-Linf <= 1e-12 (fp64; averaging stencil, no growth);
+  ssg    (staggered-grid elastic, fp32, 2 stages, 9 in-place fields): max|gpu-ref| / max|ref| <= 2e-5
+         per field after the run.
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).resolve().parent / "golden"
+INDEX = json.load(open(G / "index.json"))
+
+
+def make(stencil, size, opts=""):
+    from yask_amd import yk_factory
+    fac = yk_factory(stencil)
+    env = fac.new_env()
+    soln = fac.new_solution(env)
+    soln.set_overall_domain_size_vec(list(size))
+    if opts:
+        assert soln.apply_command_line_options(opts) == ""
+    soln.prepare_solution()
+    init = O.DEFAULT_INIT[stencil]
+    for v in soln.get_vars():
+        v.set_elements_hash(*init[v.get_name()], hash_id=O.VAR_IDS[stencil][v.get_name()])
+    return soln
+
+
+def domain_slice(soln, var, t):
+    n = soln.get_overall_domain_size_vec()
+    has_t = var.get_num_dims() == 4
+    first = ([t] if has_t else []) + [0, 0, 0]
+    last = ([t] if has_t else []) + [x - 1 for x in n]
+    a = var.get_elements_in_slice(first, last)
+    return a[0] if has_t else a
+
+
+def variant_names(stencil, part=0):
+    from yask_amd import yk_factory
+    fac = yk_factory(stencil)
+    s = fac.new_solution(fac.new_env())
+    return [n for n in s.get_kernel_variant_names(part) if not n.startswith("abl")]
+
+
+# ------------------------------------------------------------------ 3axis fp64
+def test_axis3_every_variant_matches_oracle(gpu):
+    size, steps = (21, 35, 70), 3          # ragged vs every tile; z not a multiple of the 2-wide vector
+    ref = O.run_axis3(size, steps)
+    for name in variant_names("3axis"):
+        soln = make("3axis", size, f"-hip_variant {name}")
+        assert soln.get_element_bytes() == 8
+        soln.run_solution(0, steps - 1)
+        A = soln.get_var("A")
+        for t in (steps - 1, steps):
+            err = O.rel_linf(domain_slice(soln, A, t), ref[("A", t)])
+            assert err <= 1e-12, (name, t, err)
+        soln.end_solution()
+
+
+@pytest.mark.parametrize("name", [n for n in INDEX if INDEX[n]["stencil"] == "3axis"])
+def test_axis3_matches_reference_golden(gpu, name):
+    meta = INDEX[name]
+    z = np.load(G / f"{name}.npz")
+    soln = make("3axis", meta["size"])
+    soln.run_solution(0, meta["steps"] - 1)
+    A = soln.get_var("A")
+    for t in (meta["steps"] - 1, meta["steps"]):
+        assert O.rel_linf(domain_slice(soln, A, t), z[f"A@{t}"]) <= 1e-12
+
+
+def test_axis3_constant_field_is_a_fixed_point(gpu):
+    """Size-independent property: the update is an average, so a constant field stays constant
+    (weights sum to 1 up to the 15-digit literal of 1/25)."""
+    soln = make("3axis", (40, 64, 256))
+    soln.get_var("A").set_all_elements_same(3.25)
+    soln.run_solution(0, 4)
+    got = domain_slice(soln, soln.get_var("A"), 5)
+    assert np.abs(got - 3.25).max() <= 1e-13
+
+
+# ------------------------------------------------------------------ ssg fp32
+def _ssg_err(soln, ref, steps):
+    worst = 0.0
+    for n in O.SSG_FIELDS:
+        got = domain_slice(soln, soln.get_var(n), steps).astype(np.float64)
+        r = ref[(n, steps)].astype(np.float64)
+        worst = max(worst, float(np.abs(got - r).max()) / max(1e-30, float(np.abs(r).max())))
+    return worst
+
+
+def test_ssg_every_variant_matches_oracle(gpu):
+    size, steps = (19, 22, 37), 2
+    ref = O.run_ssg(size, steps)
+    names0, names1 = variant_names("ssg", 0), variant_names("ssg", 1)
+    for name in sorted(set(names0) | set(names1)):
+        soln = make("ssg", size, f"-hip_variant {name}")
+        soln.run_solution(0, steps - 1)
+        err = _ssg_err(soln, ref, steps)
+        assert err <= 2e-5, (name, err)
+        soln.end_solution()
+
+
+@pytest.mark.parametrize("name", [n for n in INDEX if INDEX[n]["stencil"] == "ssg"])
+def test_ssg_matches_reference_golden(gpu, name):
+    meta = INDEX[name]
+    z = np.load(G / f"{name}.npz")
+    soln = make("ssg", meta["size"])
+    st = meta["steps"]
+    soln.run_solution(0, st - 1)
+    for n in O.SSG_FIELDS:
+        v = soln.get_var(n)
+        assert v.get_first_valid_step_index() == st and v.get_last_valid_step_index() == st   # 1 slot, in place
+        got = domain_slice(soln, v, st).astype(np.float64)
+        r = z[f"{n}@{st}"].astype(np.float64)
+        assert np.abs(got - r).max() / max(1e-30, np.abs(r).max()) <= 2e-5, n
+    for n in O.SSG_COEFFS:
+        assert np.array_equal(domain_slice(soln, soln.get_var(n), 0), z[f"{n}@0"])
+
+
+def test_ssg_stats_and_stage_structure(gpu):
+    soln = make("ssg", (16, 16, 32))
+    soln.run_solution(0, 1)
+    st = soln.get_stats()
+    assert st.get_num_steps_done() == 2
+    assert st.get_num_writes_done() == 2 * 9 * 16 * 16 * 32          # 3 + 6 writes per point-step
+    assert st.get_est_fp_ops_done() == 2 * (129 + 158) * 16 * 16 * 32

@@ -1,0 +1,497 @@
+// YaskHip.cpp -- implementation of the 'cdna4_hip' format-target (see YaskHip.hpp).
+#include "Print.hpp"
+#include "ExprUtils.hpp"
+#include "Eqs.hpp"
+#include "Solution.hpp"
+#include "YaskHip.hpp"
+
+#include <iomanip>
+#include <map>
+#include <set>
+#include <sstream>
+
+namespace yask {
+
+    namespace {
+
+        // Constants are printed exactly like the reference's generated code prints them
+        // (CppPrintHelper::format_real, src/compiler/lib/Cpp.cpp:39-52): 15 significant digits.
+        string fmt_real(double v) {
+            if (double(int(v)) == v)
+                return to_string(int(v));
+            ostringstream oss;
+            oss << setprecision(15) << scientific << v;
+            return oss.str();
+        }
+
+        struct Group {
+            Var* var;
+            int dt;          // step offset (0 if no step dim)
+            bool has_step;
+            vector<int> misc; // const indices of misc dims, in var-dim order
+            bool operator<(const Group& o) const {
+                if (var != o.var) return var < o.var;
+                if (dt != o.dt) return dt < o.dt;
+                return misc < o.misc;
+            }
+        };
+        struct Off { int g, d[3]; };
+
+        // Everything the emitters need to know about the dims.
+        struct DimCtx {
+            const Dimensions& dims;
+            DimCtx(const Dimensions& d) : dims(d) {}
+            int domain_idx(const string& n) const { return dims._domain_dims.lookup_posn(n); }
+        };
+
+        // Decompose a var point into (group, domain offsets).
+        bool point_info(const DimCtx& dc, VarPoint* vp, Group& g, int ofs[3]) {
+            g.var = vp->_get_var();
+            g.dt = 0;
+            g.has_step = false;
+            g.misc.clear();
+            ofs[0] = ofs[1] = ofs[2] = 0;
+            for (auto& dim : g.var->get_dims()) {
+                auto& dn = dim->_get_name();
+                auto type = dim->get_type();
+                if (type == STEP_INDEX) {
+                    auto* p = vp->get_arg_offsets().lookup(dn);
+                    if (!p) return false;
+                    g.has_step = true;
+                    g.dt = *p;
+                } else if (type == DOMAIN_INDEX) {
+                    auto* p = vp->get_arg_offsets().lookup(dn);
+                    if (!p) return false;       // not a simple offset from the index
+                    int di = dc.domain_idx(dn);
+                    if (di < 0 || di > 2) return false;
+                    ofs[di] = *p;
+                } else {
+                    auto* p = vp->get_arg_consts().lookup(dn);
+                    if (!p) return false;
+                    g.misc.push_back(*p);
+                }
+            }
+            return true;
+        }
+
+        // Linear form of a sub-expression: sum of coef * read(group, offset).
+        struct LinForm {
+            bool ok = false;
+            int g = -1;
+            map<vector<int>, double> terms;   // (dx,dy,dz) -> coef
+        };
+
+        class HipEmitter : public ExprVisitor {
+        public:
+            const DimCtx& dc;
+            vector<Group> groups;            // access groups of the part being emitted
+            vector<Off> reads;               // distinct reads
+            vector<int> writes;              // groups written
+            ostringstream body;              // statements
+            map<string, string> memo;        // expr string -> temp name
+            int ntemps = 0;
+            const Expr* lin_node = 0;        // node to be replaced by `lin_sum` (eval_lin)
+            bool failed = false;
+            string fail_why;
+
+            HipEmitter(const DimCtx& d) : dc(d) {}
+
+            int group_of(const Group& g) {
+                for (size_t i = 0; i < groups.size(); i++)
+                    if (!(groups[i] < g) && !(g < groups[i])) return (int)i;
+                groups.push_back(g);
+                return (int)groups.size() - 1;
+            }
+            void note_read(int g, const int* o) {
+                for (auto& r : reads)
+                    if (r.g == g && r.d[0] == o[0] && r.d[1] == o[1] && r.d[2] == o[2]) return;
+                reads.push_back(Off{g, {o[0], o[1], o[2]}});
+            }
+            string temp(const string& key, const string& rhs) {
+                auto it = memo.find(key);
+                if (it != memo.end()) return it->second;
+                string n = "e" + to_string(++ntemps);
+                body << "        V " << n << " = " << rhs << ";\n";
+                memo[key] = n;
+                return n;
+            }
+            string fail(const string& why) { failed = true; if (fail_why.empty()) fail_why = why; return "V(0)"; }
+
+            string visit(ConstExpr* ce) override { return "real_t(" + fmt_real(ce->get_num_val()) + ")"; }
+            string visit(CodeExpr* ce) override { return fail("hand-written code expression"); }
+            string visit(IndexExpr* ie) override {
+                auto type = ie->get_type();
+                if (type == DOMAIN_INDEX) return "a.template idx<" + to_string(dc.domain_idx(ie->_get_name())) + ">()";
+                if (type == STEP_INDEX) return "a.step()";
+                return fail("misc index used as a value");
+            }
+            string visit(VarPoint* vp) override {
+                if (lin_node == vp) return "lin_sum";
+                Group g; int o[3];
+                if (!point_info(dc, vp, g, o)) return fail("var index that is not 'dim +/- const'");
+                int gi = group_of(g);
+                note_read(gi, o);
+                return "a.template rd<" + to_string(gi) + ", " + to_string(o[0]) + ", " + to_string(o[1]) + ", " + to_string(o[2]) + ">()";
+            }
+            string visit(UnaryNumExpr* ue) override {
+                if (lin_node == ue) return "lin_sum";
+                string r = ue->_get_rhs()->accept(this);
+                return temp(ue->make_str(), ue->get_op_str() + "(" + r + ")");
+            }
+            string visit(BinaryNumExpr* be) override {
+                if (lin_node == be) return "lin_sum";
+                string l = be->_get_lhs()->accept(this);
+                string r = be->_get_rhs()->accept(this);
+                if (be->get_op_str() == "%") return fail("modulo operator");
+                return temp(be->make_str(), l + " " + be->get_op_str() + " " + r);
+            }
+            string visit(CommutativeExpr* ce) override {
+                if (lin_node == ce) return "lin_sum";
+                string s;
+                for (auto& op : ce->get_ops()) {
+                    string o = op->accept(this);
+                    s += (s.empty() ? "" : " " + ce->get_op_str() + " ") + o;
+                }
+                return temp(ce->make_str(), s);
+            }
+            string visit(FuncExpr* fe) override {
+                string s = "ykh::fn_" + fe->get_op_str() + "(";
+                bool first = true;
+                for (auto& op : fe->get_ops()) { s += (first ? "" : ", ") + op->accept(this); first = false; }
+                return temp(fe->make_str(), s + ")");
+            }
+            string visit(UnaryNum2BoolExpr*) override { return fail("boolean expression in a value"); }
+            string visit(UnaryBoolExpr*) override { return fail("boolean expression in a value"); }
+            string visit(BinaryNum2BoolExpr*) override { return fail("boolean expression in a value"); }
+            string visit(BinaryBoolExpr*) override { return fail("boolean expression in a value"); }
+            string visit(EqualsExpr* ee) override {
+                string rhs = ee->_get_rhs()->accept(this);
+                Group g; int o[3];
+                VarPoint* lhs = ee->_get_lhs().get();
+                if (!point_info(dc, lhs, g, o) || o[0] || o[1] || o[2]) return fail("write that is not at the centre point");
+                int gi = group_of(g);
+                bool have = false;
+                for (int w : writes) have |= (w == gi);
+                if (!have) writes.push_back(gi);
+                body << "        a.template wr<" << gi << ">(" << rhs << ");\n";
+                return "";
+            }
+        };
+
+        // Linear-form analysis (bottom-up, no code generation).
+        class LinAnalyzer {
+        public:
+            const DimCtx& dc;
+            HipEmitter& em;     // for group numbering shared with the emitted code
+            LinAnalyzer(const DimCtx& d, HipEmitter& e) : dc(d), em(e) {}
+
+            LinForm analyze(Expr* e) {
+                LinForm lf;
+                if (auto* vp = dynamic_cast<VarPoint*>(e)) {
+                    Group g; int o[3];
+                    if (!point_info(dc, vp, g, o)) return lf;
+                    lf.ok = true;
+                    lf.g = em.group_of(g);
+                    lf.terms[{o[0], o[1], o[2]}] = 1.0;
+                    return lf;
+                }
+                if (auto* ce = dynamic_cast<CommutativeExpr*>(e)) {
+                    if (ce->get_op_str() == "+") {
+                        lf.ok = true;
+                        for (auto& op : ce->get_ops()) {
+                            LinForm s = analyze(op.get());
+                            if (!s.ok || (lf.g >= 0 && s.g != lf.g)) { lf.ok = false; return lf; }
+                            lf.g = s.g;
+                            for (auto& t : s.terms) lf.terms[t.first] += t.second;
+                        }
+                        return lf;
+                    }
+                    if (ce->get_op_str() == "*") {
+                        double k = 1.0;
+                        LinForm inner;
+                        int nlin = 0;
+                        for (auto& op : ce->get_ops()) {
+                            if (op->is_const_val()) k *= op->get_num_val();
+                            else { inner = analyze(op.get()); nlin++; }
+                        }
+                        if (nlin != 1 || !inner.ok) return lf;
+                        lf = inner;
+                        for (auto& t : lf.terms) t.second *= k;
+                        return lf;
+                    }
+                    return lf;
+                }
+                if (auto* ue = dynamic_cast<UnaryNumExpr*>(e)) {
+                    // note: BinaryNumExpr derives from UnaryNumExpr; test it first
+                    if (auto* be = dynamic_cast<BinaryNumExpr*>(e)) {
+                        LinForm l = analyze(be->_get_lhs().get());
+                        if (be->get_op_str() == "-") {
+                            LinForm r = analyze(be->_get_rhs().get());
+                            if (!l.ok || !r.ok || l.g != r.g) return lf;
+                            lf = l;
+                            for (auto& t : r.terms) lf.terms[t.first] -= t.second;
+                            return lf;
+                        }
+                        if (be->get_op_str() == "/" && l.ok && be->_get_rhs()->is_const_val()) {
+                            lf = l;
+                            for (auto& t : lf.terms) t.second /= be->_get_rhs()->get_num_val();
+                            return lf;
+                        }
+                        return lf;
+                    }
+                    if (ue->get_op_str() == "-") {
+                        lf = analyze(ue->_get_rhs().get());
+                        for (auto& t : lf.terms) t.second = -t.second;
+                        return lf;
+                    }
+                }
+                return lf;
+            }
+
+            static bool off_centre(const LinForm& lf) {
+                for (auto& t : lf.terms)
+                    if (t.first[0] || t.first[1] || t.first[2]) return true;
+                return false;
+            }
+
+            // Maximal linear nodes that contain off-centre reads.
+            void collect(Expr* e, vector<pair<Expr*, LinForm>>& out) {
+                LinForm lf = analyze(e);
+                if (lf.ok) {
+                    if (off_centre(lf)) out.push_back({e, lf});
+                    return;
+                }
+                if (auto* ce = dynamic_cast<CommutativeExpr*>(e)) { for (auto& op : ce->get_ops()) collect(op.get(), out); return; }
+                if (auto* fe = dynamic_cast<FuncExpr*>(e)) { for (auto& op : fe->get_ops()) collect(op.get(), out); return; }
+                if (auto* be = dynamic_cast<BinaryNumExpr*>(e)) { collect(be->_get_lhs().get(), out); collect(be->_get_rhs().get(), out); return; }
+                if (auto* ue = dynamic_cast<UnaryNumExpr*>(e)) { collect(ue->_get_rhs().get(), out); return; }
+            }
+        };
+
+        string c_ident(const string& s) {
+            string r;
+            for (char c : s) r += (isalnum((unsigned char)c) ? c : '_');
+            return r;
+        }
+
+    } // anon namespace.
+
+    void YASKHipPrinter::print(ostream& os) {
+        DimCtx dc(_dims);
+        const string sname = _stencil._get_name();
+        const int nddims = _dims._domain_dims.get_num_dims();
+        if (nddims < 1 || nddims > 3)
+            THROW_YASK_EXCEPTION("the 'cdna4_hip' target supports 1 to 3 domain dimensions; solution '" + sname +
+                                 "' has " + to_string(nddims));
+        const int ebytes = _settings._elem_bytes;
+        const string real_t = ebytes == 4 ? "float" : "double";
+
+        os << "// Automatically generated by the YASK stencil compiler, format-target 'cdna4_hip'\n"
+              "// (yask_amd/compiler/YaskHip.cpp).  Stencil solution '" << sname << "', " << ebytes << "-byte reals.\n"
+              "// DO NOT EDIT: regenerate with `make -C yask_amd/compiler gen`.\n"
+              "#pragma once\n#include <hip/hip_runtime.h>\n#include \"ykh_meta.hpp\"\n\n"
+              "namespace ykh_gen_" << c_ident(sname) << " {\nusing namespace ykh;\ntypedef " << real_t << " real_t;\n\n";
+
+        // ---- dims: step, domain (outer -> inner), misc.
+        vector<string> dnames;
+        map<string, int> dim_idx;
+        os << "static constexpr DimMeta dims[] = {\n";
+        {
+            auto add = [&](const string& n, const char* type, int di) {
+                os << "    {\"" << n << "\", " << type << ", " << di << "},\n";
+                dim_idx[n] = (int)dnames.size();
+                dnames.push_back(n);
+            };
+            add(_dims._step_dim, "DIM_STEP", -1);
+            int di = 0;
+            for (auto& d : _dims._domain_dims) add(d._get_name(), "DIM_DOMAIN", di++);
+            for (auto& d : _dims._misc_dims) add(d._get_name(), "DIM_MISC", -1);
+        }
+        os << "};\n\n";
+
+        // ---- vars.
+        vector<Var*> vlist;
+        map<Var*, int> var_idx;
+        os << "static constexpr VarMeta vars[] = {\n"
+              "    // name ndims dims step_alloc halo_l halo_r misc_first misc_last l1 scratch written\n";
+        for (auto gp : _vars) {
+            if (!gp->is_needed()) continue;
+            var_idx[gp] = (int)vlist.size();
+            vlist.push_back(gp);
+            int hl[3] = {0, 0, 0}, hr[3] = {0, 0, 0};
+            string dl, mf, ml;
+            int step_alloc = 0;
+            bool got_domain = false;
+            for (auto& dim : gp->get_dims()) {
+                auto& dn = dim->_get_name();
+                dl += (dl.empty() ? "" : ", ") + to_string(dim_idx.at(dn));
+                int f = 0, l = 0;
+                if (dim->get_type() == DOMAIN_INDEX) {
+                    got_domain = true;
+                    int di = dc.domain_idx(dn);
+                    hl[di] = _settings._halo_size > 0 ? _settings._halo_size : gp->get_halo_size(dn, true);
+                    hr[di] = _settings._halo_size > 0 ? _settings._halo_size : gp->get_halo_size(dn, false);
+                } else if (dim->get_type() == STEP_INDEX)
+                    step_alloc = gp->get_step_dim_info().step_dim_size;
+                else {
+                    auto* minp = gp->get_min_indices().lookup(dn);
+                    auto* maxp = gp->get_max_indices().lookup(dn);
+                    if (minp && maxp) { f = *minp; l = *maxp; }
+                }
+                mf += (mf.empty() ? "" : ", ") + to_string(f);
+                ml += (ml.empty() ? "" : ", ") + to_string(l);
+            }
+            if (dl.empty()) { dl = "0"; mf = "0"; ml = "0"; }
+            os << "    {\"" << gp->_get_name() << "\", " << gp->get_num_dims() << ", {" << dl << "}, " << step_alloc
+               << ", {" << hl[0] << ", " << hl[1] << ", " << hl[2] << "}, {" << hr[0] << ", " << hr[1] << ", " << hr[2] << "}, {"
+               << mf << "}, {" << ml << "}, " << (got_domain ? gp->get_l1_dist() : 0) << ", "
+               << (gp->is_scratch() ? "true" : "false") << ", "
+               << (_parts.get_output_vars().count(gp) ? "true" : "false") << "},\n";
+        }
+        os << "};\n\n";
+
+        // ---- parts, stage by stage.
+        vector<string> part_names;
+        vector<string> part_meta;
+        map<string, int> part_idx;
+        vector<pair<string, vector<int>>> stages;
+        int stage_no = 0;
+        for (auto& st : _eq_stages.get_all()) {
+            vector<int> members;
+            for (auto& part : st->get_parts()) {
+                const string pname = part->_get_name();
+                CounterVisitor stats;
+                part->visit_eqs(&stats);
+
+                HipEmitter em(dc);
+                for (auto& eq : part->get_eqs()) eq->accept(&em);
+                if (em.failed)
+                    THROW_YASK_EXCEPTION("the 'cdna4_hip' target cannot render part '" + pname + "' of solution '" +
+                                         sname + "': " + em.fail_why);
+
+                // sub-domain / step conditions: rendered as predicates over the indices.
+                string cond_code, step_cond_code;
+                bool has_cond = part->cond.get() != 0, has_step_cond = part->step_cond.get() != 0;
+
+                // linear star form?
+                bool has_lin = false;
+                LinForm lin;
+                string lin_body;
+                if (part->get_eqs().size() == 1 && !has_cond && !has_step_cond) {
+                    auto& eq = part->get_eqs().front();
+                    HipEmitter em2(dc);
+                    em2.groups = em.groups;              // same group numbering
+                    LinAnalyzer la(dc, em2);
+                    vector<pair<Expr*, LinForm>> nodes;
+                    la.collect(eq->_get_rhs().get(), nodes);
+                    if (nodes.size() == 1) {
+                        lin = nodes[0].second;
+                        bool axis = true;
+                        for (auto& t : lin.terms)
+                            if ((t.first[0] != 0) + (t.first[1] != 0) + (t.first[2] != 0) > 1) axis = false;
+                        // the star group must not be read off-centre anywhere else and must use all domain dims
+                        if (axis && em2.groups.size() == em.groups.size()) {
+                            em2.lin_node = nodes[0].first;
+                            eq->accept(&em2);
+                            bool ok = !em2.failed;
+                            for (auto& r : em2.reads)
+                                if (r.d[0] || r.d[1] || r.d[2]) ok = false;
+                            if (ok) { has_lin = true; lin_body = em2.body.str(); }
+                        }
+                    }
+                }
+
+                os << "// ////// Stencil part '" << pname << "' (stage '" << st->_get_name() << "'): " << stats.get_num_ops()
+                   << " FP operation(s), " << stats.get_num_reads() << " read(s), " << stats.get_num_writes()
+                   << " write(s) per point.\n";
+                for (auto& eq : part->get_eqs())
+                    os << "//   " << eq->make_str() << "\n";
+                os << "struct " << pname << " {\n    typedef " << real_t << " real_t;\n";
+                os << "    static constexpr int n_groups = " << em.groups.size() << ";\n"
+                      "    static constexpr AccessGroup groups[" << em.groups.size() << "] = {\n";
+                for (size_t g = 0; g < em.groups.size(); g++) {
+                    auto& G = em.groups[g];
+                    os << "        {" << var_idx.at(G.var) << ", " << G.dt << ", " << (G.has_step ? "true" : "false") << ", "
+                       << G.misc.size() << ", {";
+                    for (size_t i = 0; i < G.misc.size(); i++) os << (i ? ", " : "") << G.misc[i];
+                    os << "}},   // g" << g << ": " << G.var->_get_name();
+                    if (G.has_step) os << "(" << _dims._step_dim << (G.dt > 0 ? "+" : "") << (G.dt ? to_string(G.dt) : "") << ")";
+                    os << "\n";
+                }
+                os << "    };\n";
+                os << "    static constexpr int n_reads = " << em.reads.size() << ";\n"
+                      "    static constexpr ReadOff reads[" << (em.reads.size() ? em.reads.size() : 1) << "] = {";
+                for (size_t i = 0; i < em.reads.size(); i++) {
+                    auto& r = em.reads[i];
+                    os << (i % 6 == 0 ? "\n        " : " ") << "{" << r.g << ", " << r.d[0] << ", " << r.d[1] << ", " << r.d[2] << "}"
+                       << (i + 1 < em.reads.size() ? "," : "");
+                }
+                if (em.reads.empty()) os << "{0, 0, 0, 0}";
+                os << "};\n";
+                os << "    static constexpr int n_writes = " << em.writes.size() << ";\n"
+                      "    static constexpr int writes[" << em.writes.size() << "] = {";
+                for (size_t i = 0; i < em.writes.size(); i++) os << (i ? ", " : "") << em.writes[i];
+                os << "};\n\n";
+                os << "    // `A` supplies rd<group,dx,dy,dz>() / wr<group>() (scalar or z-vector valued).\n"
+                      "    template <class A>\n    __device__ __forceinline__ static void eval(A& a) {\n"
+                      "        typedef typename A::V V;\n" << em.body.str() << "    }\n";
+                if (has_lin) {
+                    os << "\n    // Linear star form: the off-centre reads are lin_sum = sum_i lin[i].c * g" << lin.g
+                       << "(x+dx, y+dy, z+dz).\n"
+                          "    static constexpr bool has_lin = true;\n"
+                          "    static constexpr int lin_group = " << lin.g << ";\n"
+                          "    static constexpr int n_lin = " << lin.terms.size() << ";\n"
+                          "    static constexpr LinTerm lin[" << lin.terms.size() << "] = {";
+                    size_t i = 0;
+                    for (auto& t : lin.terms) {
+                        ostringstream c;
+                        c << setprecision(17) << scientific << t.second;
+                        os << (i % 3 == 0 ? "\n        " : " ") << "{" << t.first[0] << ", " << t.first[1] << ", " << t.first[2] << ", "
+                           << c.str() << "}" << (i + 1 < lin.terms.size() ? "," : "");
+                        i++;
+                    }
+                    os << "};\n    template <class A>\n"
+                          "    __device__ __forceinline__ static void eval_lin(A& a, typename A::V lin_sum) {\n"
+                          "        typedef typename A::V V;\n" << lin_body << "    }\n";
+                } else
+                    os << "    static constexpr bool has_lin = false;\n";
+                os << "};\n\n";
+
+                ostringstream pm;
+                pm << "    {\"" << pname << "\", " << pname << "::n_groups, " << pname << "::groups, " << pname << "::n_reads, "
+                   << pname << "::reads, " << pname << "::n_writes, " << pname << "::writes,\n     " << stats.get_num_ops() << ", "
+                   << stats.get_num_reads() << ", " << stats.get_num_writes() << ", " << stage_no << ", "
+                   << (has_cond ? "true" : "false") << ", " << (has_step_cond ? "true" : "false") << "},\n";
+                part_idx[pname] = (int)part_names.size();
+                members.push_back((int)part_names.size());
+                part_names.push_back(pname);
+                part_meta.push_back(pm.str());
+                if (has_cond || has_step_cond)
+                    THROW_YASK_EXCEPTION("the 'cdna4_hip' target does not yet render sub-domain or step conditions (part '" +
+                                         pname + "' of solution '" + sname + "')");
+            }
+            if (!st->is_scratch() || !members.empty())
+                stages.push_back({st->_get_name(), members});
+            stage_no++;
+        }
+
+        os << "static constexpr PartMeta parts[] = {\n";
+        for (auto& s : part_meta) os << s;
+        os << "};\n";
+        for (auto& s : stages) {
+            os << "static constexpr int " << c_ident(s.first) << "_parts[] = {";
+            for (size_t i = 0; i < s.second.size(); i++) os << (i ? ", " : "") << s.second[i];
+            os << "};\n";
+        }
+        os << "static constexpr StageMeta stages[] = {\n";
+        for (auto& s : stages) os << "    {\"" << s.first << "\", " << s.second.size() << ", " << c_ident(s.first) << "_parts},\n";
+        os << "};\n\n";
+        os << "static constexpr SolnMeta soln = {\"" << sname << "\", \"" << _stencil.get_description() << "\", \"cdna4_hip\", "
+           << ebytes << ", " << dnames.size() << ", dims, " << (_dims._step_dir < 0 ? -1 : 1) << ", " << vlist.size() << ", vars, "
+           << part_names.size() << ", parts, " << stages.size() << ", stages};\n\n"
+              "// part list for the kernel registry (stencil_<name>.hip)\n#define YKH_FOR_EACH_PART(M)";
+        for (auto& p : part_names) os << " M(" << p << ")";
+        os << "\n\n}  // namespace ykh_gen_" << c_ident(sname) << "\n";
+    }
+
+} // namespace yask.

@@ -142,6 +142,10 @@ struct NaiveAcc {
         T* p = (T*)a.ptr[G];
         p[(idx_t)x * a.gsx[G] + (idx_t)y * a.gsy[G] + (idx_t)z * a.gsz[G]] = v;
     }
+    // global index of the point in domain dim D / the evaluation step, as values
+    template <int D>
+    __device__ __forceinline__ V idx() const { return V(D == 0 ? x + a.ofs_x : (D == 1 ? y + a.ofs_y : z + a.ofs_z)); }
+    __device__ __forceinline__ V step() const { return V(a.t); }
 };
 
 template <class P>

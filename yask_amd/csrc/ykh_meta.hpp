@@ -39,6 +39,8 @@ struct AccessGroup {
     int var;        // index into SolnMeta::vars
     int dt;         // step offset relative to the evaluation step t (0 if var has no step dim)
     bool has_step;
+    int nmisc = 0;                    // constant indices of the var's misc dims, in var-dim order
+    int misc[MAX_VAR_DIMS] = {};
 };
 
 struct ReadOff {
