@@ -76,6 +76,29 @@ int yk_env_set_transport(yk_env_h env, yk_exchange_fn start, yk_exchange_fn wait
 int yk_rccl_get_unique_id(void* unique_id_128);
 int yk_env_init_rccl(yk_env_h env, const void* unique_id_128, int rank, int num_ranks);
 
+/* ---- decomposition planning: pure index arithmetic, callable WITHOUT a GPU (used by multi-process
+ * CPU tests and by hosts that want to size buffers before creating a solution).  Same code that
+ * prepare_solution() runs.  Replaces: StencilContext::setup_rank (src/kernel/lib/setup.cpp:169-524),
+ * get_compact_factors (src/common/tuple.cpp:355-430), halo-buffer geometry alloc_mpi_data
+ * (src/kernel/lib/alloc.cpp:456-859). Domain dims are indexed 0..ndims-1 outer->inner (x,y,z). */
+typedef struct {
+    yk_idx_t global_size[3];      /* in/out: overall-domain size (0 = derive from local_size) */
+    yk_idx_t local_size[3];       /* in/out: rank-domain size (0 = derive from global_size)   */
+    yk_idx_t num_ranks[3];        /* in/out: rank grid (0 = choose the most compact one)      */
+    yk_idx_t rank_index[3];       /* out: this rank's coordinates in the grid                 */
+    yk_idx_t rank_offset[3];      /* out: global index of this rank's first domain point      */
+    int num_neighbors;            /* out */
+    int neighbor_rank[26];
+    int neighbor_offset[26][3];   /* each in {-1,0,+1} */
+} yk_rank_plan_t;
+int yk_plan_rank(int ndims, int num_ranks, int rank, yk_rank_plan_t* plan);
+typedef struct { yk_idx_t first[3], size[3]; } yk_box_t;   /* rank-local indices: 0 = first domain point */
+/* Slab of a var (halo sizes, L1 norm as yk_var reports them) exchanged with the neighbour at `offset`:
+ * sending != 0 -> the part of my domain the neighbour needs; else -> the part of my halo it fills.
+ * Returns 1 and fills *box if there is one, 0 if nothing travels, <0 on error. */
+int yk_plan_halo_slab(int ndims, const yk_rank_plan_t* plan, const int* neighbor_offset,
+                      const yk_idx_t* halo_left, const yk_idx_t* halo_right, int l1_norm, int sending, yk_box_t* box);
+
 /* ---- solution: replaces yk_solution, include/aux/yk_solution_api.hpp:82-1292 ---- */
 const char* yk_solution_get_name(yk_soln_h s);                               /* :90 */
 const char* yk_solution_get_description(yk_soln_h s);                        /* :98 */

@@ -1,0 +1,245 @@
+"""N>1 path on CPU (no GPU): the decomposition/halo-geometry code that prepare_solution() runs on every
+GPU is exported device-free (yk_plan_rank / yk_plan_halo_slab, yask_amd/csrc/ykh_plan.cpp); here it drives
+(a) rule checks against the reference's documented behaviour,
+(b) an in-process emulation of a 2x2x2 rank grid, and
+(c) a real 2-process `gloo` run: each rank owns a sub-box, exchanges the planned halo slabs with
+    torch.distributed and steps its box with the oracle; the union must equal the single-rank oracle
+    bit-for-bit (same arithmetic, same order, halos carry exactly the neighbour's values).
+The data path on the GPUs (pack kernel -> RCCL -> unpack kernel) is covered by tests/test_multirank_gpu.py.
+"""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from yask_amd import _capi
+
+H = 8   # iso3dfd halo
+
+
+def _lib():
+    return _capi.load("iso3dfd")      # dlopen only: no device is touched
+
+
+def plan(nranks, rank, global_size=None, local_size=None, num_ranks=(0, 0, 0)):
+    p = _capi.RankPlan()
+    for d in range(3):
+        p.global_size[d] = (global_size or (0, 0, 0))[d]
+        p.local_size[d] = (local_size or (0, 0, 0))[d]
+        p.num_ranks[d] = num_ranks[d]
+    rc = _lib().yk_plan_rank(3, nranks, rank, C.byref(p))
+    if rc != 0:
+        msg = _lib().yk_last_error().decode()
+        _lib().yk_clear_error()
+        raise RuntimeError(msg)
+    return p
+
+
+def slab(p, ofs, halo=(H, H, H), l1=1, sending=True):
+    b = _capi.Box()
+    o = (C.c_int * 3)(*ofs)
+    hl = (_capi.idx_t * 3)(*halo)
+    hr = (_capi.idx_t * 3)(*halo)
+    rc = _lib().yk_plan_halo_slab(3, C.byref(p), o, hl, hr, l1, 1 if sending else 0, C.byref(b))
+    assert rc >= 0
+    return (tuple(b.first), tuple(b.size)) if rc == 1 else None
+
+
+def neighbors(p):
+    return [(p.neighbor_rank[i], tuple(p.neighbor_offset[i])) for i in range(p.num_neighbors)]
+
+
+# ------------------------------------------------------------------ (a) rules
+def test_compact_rank_grids_match_reference():
+    # probed on the reference: 4 ranks -> x=2*y=2*z=1; 8 -> 2*2*2
+    assert tuple(plan(4, 0, (64, 64, 64)).num_ranks) == (2, 2, 1)
+    assert tuple(plan(8, 0, (64, 64, 64)).num_ranks) == (2, 2, 2)
+    assert tuple(plan(2, 0, (64, 64, 64)).num_ranks)[::-1].count(1) == 2
+    # a partly specified grid is completed; a contradictory one is re-factored without the pre-set
+    # values, exactly as Tuple::get_compact_factors does (src/common/tuple.cpp:378-430: "keep", then not)
+    assert tuple(plan(8, 0, (64, 64, 64), num_ranks=(8, 0, 0)).num_ranks) == (8, 1, 1)
+    assert tuple(plan(8, 0, (64, 64, 64), num_ranks=(3, 1, 1)).num_ranks) == (2, 2, 2)
+    with pytest.raises(RuntimeError, match="invalid rank"):
+        plan(4, 4, (64, 64, 64))
+
+
+def test_rank_coordinates_first_dim_fastest_and_remainder_on_last_rank():
+    # API doc example: x varies fastest (include/aux/yk_solution_api.hpp:458-467)
+    coords = [tuple(plan(6, r, (100, 90, 80), num_ranks=(2, 3, 1)).rank_index) for r in range(6)]
+    assert coords == [(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (0, 2, 0), (1, 2, 0)]
+    # local size = ceil(global/n); the last rank takes what is left (setup.cpp:478-495)
+    sizes = [plan(3, r, (100, 64, 64), num_ranks=(3, 1, 1)) for r in range(3)]
+    assert [s.local_size[0] for s in sizes] == [34, 34, 32]
+    assert [s.rank_offset[0] for s in sizes] == [0, 34, 68]
+    # local sizes given -> global derived
+    p = plan(4, 3, local_size=(10, 20, 30), num_ranks=(2, 2, 1))
+    assert tuple(p.global_size) == (20, 40, 30) and tuple(p.rank_offset) == (10, 20, 0)
+
+
+def test_neighbor_sets_and_face_only_exchange_for_l1_1():
+    p = plan(8, 0, (64, 64, 64))
+    nb = neighbors(p)
+    assert len(nb) == 7                       # a corner rank of a 2x2x2 grid
+    faces = [n for n in nb if sum(abs(x) for x in n[1]) == 1]
+    assert sorted(r for r, _ in faces) == [1, 2, 4]
+    for r, o in nb:
+        s = slab(p, o, l1=1)
+        assert (s is not None) == (sum(abs(x) for x in o) == 1)   # iso3dfd p: faces only
+        if s is not None:
+            d = [i for i in range(3) if o[i]][0]
+            assert s[1][d] == H and all(s[1][k] == 32 for k in range(3) if k != d)
+
+
+# ------------------------------------------------------------------ (b) in-process emulation, 2x2x2, L1 = 2
+def _exchange_all(plans, arrays, halo, l1):
+    """Copy every planned send slab into the matching receive slab (what pack->transport->unpack does)."""
+    n = len(plans)
+    msgs = {}
+    for r in range(n):
+        for nr, o in neighbors(plans[r]):
+            s = slab(plans[r], o, halo=(halo,) * 3, l1=l1, sending=True)
+            if s is None:
+                continue
+            (f, sz) = s
+            a = arrays[r]
+            msgs[(r, nr)] = a[tuple(slice(halo + f[d], halo + f[d] + sz[d]) for d in range(3))].copy()
+    for r in range(n):
+        for nr, o in neighbors(plans[r]):
+            s = slab(plans[r], o, halo=(halo,) * 3, l1=l1, sending=False)
+            if s is None:
+                assert (nr, r) not in msgs
+                continue
+            (f, sz) = s
+            m = msgs[(nr, r)]
+            assert m.shape == tuple(sz), "send slab of the neighbour and my receive slab disagree"
+            arrays[r][tuple(slice(halo + f[d], halo + f[d] + sz[d]) for d in range(3))] = m
+
+
+def test_diagonal_exchange_fills_every_in_domain_halo_cell():
+    g, halo = (20, 24, 28), 3
+    plans = [plan(8, r, g) for r in range(8)]
+    arrays = []
+    for p in plans:
+        ls, ofs = tuple(p.local_size), tuple(p.rank_offset)
+        full = O.fill(ls, halo, 5, 0, 0.0, 1.0, dtype=np.float32, origin=ofs)
+        a = np.full_like(full, np.nan)
+        a[halo:-halo, halo:-halo, halo:-halo] = full[halo:-halo, halo:-halo, halo:-halo]
+        arrays.append((a, full))
+    work = [a for a, _ in arrays]
+    _exchange_all(plans, work, halo, l1=2)
+    for (a, full), p in zip(arrays, plans):
+        ls, ofs = tuple(p.local_size), tuple(p.rank_offset)
+        # global coordinates of every cell of the halo'd box
+        idx = np.meshgrid(*[np.arange(-halo, ls[d] + halo) + ofs[d] for d in range(3)], indexing="ij")
+        inside = np.ones(a.shape, bool)
+        for d in range(3):
+            inside &= (idx[d] >= 0) & (idx[d] < g[d])
+        # cells whose offset from the local box is non-zero in <= 2 dims are reachable with L1 = 2
+        outside_dims = sum(((idx[d] < ofs[d]) | (idx[d] >= ofs[d] + ls[d])).astype(int) for d in range(3))
+        need = inside & (outside_dims <= 2)
+        assert not np.isnan(a[need]).any()
+        assert np.array_equal(a[need], full[need])
+
+
+def _emulate_iso3dfd(nranks, g, steps, num_ranks=(0, 0, 0)):
+    plans = [plan(nranks, r, g, num_ranks=num_ranks) for r in range(nranks)]
+    ids = O.VAR_IDS["iso3dfd"]
+    init = O.DEFAULT_INIT["iso3dfd"]
+    st = []
+    for p in plans:
+        ls, ofs = tuple(p.local_size), tuple(p.rank_offset)
+        pp = [O.fill(ls, H, ids["p"], s, *init["p"], dtype=np.float32, origin=ofs) for s in (0, 1)]
+        v = O.fill(ls, H, ids["v"], 0, *init["v"], dtype=np.float32, origin=ofs)
+        st.append((pp, v, ls))
+    fn = O.lib().yo_iso3dfd_step_f32
+    for t in range(steps):
+        for pp, v, ls in st:
+            fn(O._ptr(pp[t % 2]), O._ptr(pp[(t + 1) % 2]), O._ptr(v), C.c_int64(ls[0]), C.c_int64(ls[1]), C.c_int64(ls[2]),
+               C.c_int64(H), C.c_int(8))
+        _exchange_all(plans, [pp[(t + 1) % 2] for pp, _, _ in st], H, l1=1)
+    out = np.zeros(g, np.float32)
+    for p, (pp, v, ls) in zip(plans, st):
+        o = tuple(p.rank_offset)
+        out[o[0]:o[0] + ls[0], o[1]:o[1] + ls[1], o[2]:o[2] + ls[2]] = O.interior(pp[steps % 2], H)
+    return out
+
+
+@pytest.mark.parametrize("nranks,num_ranks", [(8, (0, 0, 0)), (3, (3, 1, 1)), (4, (1, 2, 2))])
+def test_emulated_rank_grid_equals_single_rank(nranks, num_ranks):
+    g, steps = (40, 36, 44), 3
+    ref = O.run_iso3dfd(g, steps)[("p", steps)]
+    got = _emulate_iso3dfd(nranks, g, steps, num_ranks)
+    assert np.array_equal(got, ref)          # identical arithmetic on identical inputs: bit-exact
+
+
+# ------------------------------------------------------------------ (c) real processes, gloo, world size 2
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, g, steps, num_ranks, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = plan(world, rank, g, num_ranks=num_ranks)
+        ls, ofs = tuple(p.local_size), tuple(p.rank_offset)
+        ids, init = O.VAR_IDS["iso3dfd"], O.DEFAULT_INIT["iso3dfd"]
+        pp = [O.fill(ls, H, ids["p"], s, *init["p"], dtype=np.float32, origin=ofs) for s in (0, 1)]
+        v = O.fill(ls, H, ids["v"], 0, *init["v"], dtype=np.float32, origin=ofs)
+        fn = O.lib().yo_iso3dfd_step_f32
+        for t in range(steps):
+            fn(O._ptr(pp[t % 2]), O._ptr(pp[(t + 1) % 2]), O._ptr(v), C.c_int64(ls[0]), C.c_int64(ls[1]), C.c_int64(ls[2]),
+               C.c_int64(H), C.c_int(8))
+            a = pp[(t + 1) % 2]
+            ops, recvs = [], []
+            for nr, o in neighbors(p):
+                s = slab(p, o, sending=True)
+                r = slab(p, o, sending=False)
+                if s is not None:
+                    (f, sz) = s
+                    buf = torch.from_numpy(np.ascontiguousarray(a[tuple(slice(H + f[d], H + f[d] + sz[d]) for d in range(3))]))
+                    ops.append(dist.P2POp(dist.isend, buf, nr))
+                if r is not None:
+                    (f, sz) = r
+                    rb = torch.empty(tuple(sz), dtype=torch.float32)
+                    ops.append(dist.P2POp(dist.irecv, rb, nr))
+                    recvs.append((f, sz, rb))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            for f, sz, rb in recvs:
+                a[tuple(slice(H + f[d], H + f[d] + sz[d]) for d in range(3))] = rb.numpy()
+        q.put((rank, ofs, ls, O.interior(pp[steps % 2], H).copy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_ranks", [(2, 1, 1), (1, 1, 2)])
+def test_two_process_gloo_halo_exchange_equals_single_rank(num_ranks):
+    import torch.multiprocessing as mp
+    g, steps = (34, 30, 40), 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, g, steps, num_ranks, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    parts = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = O.run_iso3dfd(g, steps)[("p", steps)]
+    got = np.zeros(g, np.float32)
+    for _, o, ls, a in parts:
+        got[o[0]:o[0] + ls[0], o[1]:o[1] + ls[1], o[2]:o[2] + ls[2]] = a
+    assert np.array_equal(got, ref)

@@ -1,0 +1,133 @@
+"""N>1 data path on the GPU: two ranks (two processes) share the one GPU of the test box and run the REAL
+library path -- exterior/interior split, pack kernels, halo transport, unpack kernels, dirty-flag
+bookkeeping, comm/compute stream ordering -- with the host-staged torch.distributed/gloo transport
+(RCCL needs one device per rank, so its send/recv calls themselves are exercised only by the driver's
+multi-GPU bench).  The union of the rank domains must equal the single-rank GPU result BIT-exactly (same
+kernel, same per-point arithmetic) and the oracle within the stated tolerance."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _fields(stencil):
+    return {"iso3dfd": ["p"], "3axis": ["A"], "ssg": O.SSG_FIELDS}[stencil]
+
+
+def _run_rank(stencil, g, steps, opts, nr):
+    """Create, init and run a solution in this process; returns (soln, local first index, local sizes)."""
+    from yask_amd import yk_factory, dist as ydist
+    fac = yk_factory(stencil)
+    env, _ = ydist.new_env(fac, "torch")
+    soln = fac.new_solution(env)
+    soln.set_overall_domain_size_vec(list(g))
+    if nr is not None:
+        soln.set_num_ranks_vec(list(nr))
+    if opts:
+        assert soln.apply_command_line_options(opts) == ""
+    soln.prepare_solution()
+    init = O.DEFAULT_INIT[stencil]
+    for v in soln.get_vars():
+        v.set_elements_hash(*init[v.get_name()], hash_id=O.VAR_IDS[stencil][v.get_name()])
+    soln.run_solution(0, steps - 1)
+    return soln
+
+
+def _local_result(soln, stencil, steps):
+    f = soln.get_first_rank_domain_index_vec()
+    l = soln.get_last_rank_domain_index_vec()
+    out = {}
+    for n in _fields(stencil):
+        v = soln.get_var(n)
+        a = v.get_elements_in_slice([steps] + f, [steps] + l)[0]
+        out[n] = a
+    return f, out
+
+
+def _worker(rank, world, port, stencil, g, steps, opts, nr, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from yask_amd import dist as ydist
+    torch.cuda.set_device(0)
+    ydist.init_process_group(backend="gloo")
+    try:
+        soln = _run_rank(stencil, g, steps, opts, nr)
+        assert soln.get_num_ranks_vec() == list(nr)
+        f, out = _local_result(soln, stencil, steps)
+        q.put((rank, f, out))
+        dist.barrier()
+        soln.end_solution()
+    finally:
+        dist.destroy_process_group()
+
+
+def _two_ranks(stencil, g, steps, opts, nr):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, stencil, g, steps, opts, nr, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    parts = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    full = {n: np.zeros(g, parts[0][2][n].dtype) for n in _fields(stencil)}
+    for _, f, out in parts:
+        for n, a in out.items():
+            full[n][f[0]:f[0] + a.shape[0], f[1]:f[1] + a.shape[1], f[2]:f[2] + a.shape[2]] = a
+    return full
+
+
+def _single(stencil, g, steps, opts):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    soln = _run_rank(stencil, g, steps, opts, None)
+    _, out = _local_result(soln, stencil, steps)
+    soln.end_solution()
+    return out
+
+
+@pytest.mark.parametrize("nr,opts", [((2, 1, 1), ""), ((1, 1, 2), ""), ((1, 2, 1), "-no-overlap_comms"),
+                                     ((2, 1, 1), "-min_exterior 12 -hip_variant star25d_z128_y16_r1_u")])
+def test_iso3dfd_two_ranks_equal_one_rank(gpu, nr, opts):
+    g, steps = (48, 40, 72), 4
+    two = _two_ranks("iso3dfd", g, steps, opts, nr)
+    one = _single("iso3dfd", g, steps, opts)
+    assert np.array_equal(two["p"], one["p"])
+    ref = O.run_iso3dfd(g, steps)[("p", steps)]
+    assert O.rel_linf(two["p"], ref) <= 2e-5
+
+
+def test_ssg_two_ranks_equal_one_rank(gpu):
+    """9 in-place fields, 2 stages with an exchange after each, asymmetric halos (3/4), `mu` read
+    diagonally (L1 norm 2 -> edge neighbours, here none with 2 ranks, but the boundary extension applies)."""
+    g, steps = (40, 24, 36), 3
+    two = _two_ranks("ssg", g, steps, "", (2, 1, 1))
+    one = _single("ssg", g, steps, "")
+    ref = O.run_ssg(g, steps)
+    for n in O.SSG_FIELDS:
+        assert np.array_equal(two[n], one[n]), n
+        r = ref[(n, steps)].astype(np.float64)
+        assert np.abs(two[n].astype(np.float64) - r).max() / max(1e-30, np.abs(r).max()) <= 2e-5, n
+
+
+def test_axis3_two_ranks_y_split(gpu):
+    g, steps = (24, 44, 40), 3
+    two = _two_ranks("3axis", g, steps, "", (1, 2, 1))
+    ref = O.run_axis3(g, steps)[("A", steps)]
+    assert O.rel_linf(two["A"], ref) <= 1e-12

@@ -42,7 +42,22 @@ _S = C.c_char_p
 _IP = C.POINTER(idx_t)
 
 # name -> (restype, argtypes); kept in the same order as the header.
+class RankPlan(C.Structure):
+    """yk_rank_plan_t"""
+    _fields_ = [("global_size", idx_t * 3), ("local_size", idx_t * 3), ("num_ranks", idx_t * 3), ("rank_index", idx_t * 3),
+                ("rank_offset", idx_t * 3), ("num_neighbors", C.c_int), ("neighbor_rank", C.c_int * 26),
+                ("neighbor_offset", (C.c_int * 3) * 26)]
+
+
+class Box(C.Structure):
+    """yk_box_t"""
+    _fields_ = [("first", idx_t * 3), ("size", idx_t * 3)]
+
+
 PROTOTYPES = {
+    "yk_plan_rank": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(RankPlan)]),
+    "yk_plan_halo_slab": (C.c_int, [C.c_int, C.POINTER(RankPlan), C.POINTER(C.c_int), C.POINTER(idx_t), C.POINTER(idx_t),
+                                    C.c_int, C.c_int, C.POINTER(Box)]),
     "yk_last_error": (_S, []),
     "yk_last_error_code": (C.c_int, []),
     "yk_clear_error": (None, []),

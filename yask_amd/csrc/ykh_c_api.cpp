@@ -338,6 +338,54 @@ int yk_solution_time_part(yk_soln_h s, int part, int variant, yk_idx_t xchunk, y
     YK_CATCH(1)
 }
 
+// ---- device-free planning
+int yk_plan_rank(int ndims, int num_ranks, int rank, yk_rank_plan_t* plan) {
+    YK_TRY
+    if (!plan || ndims < 1 || ndims > MAX_DOMAIN_DIMS) YKH_THROW("yk_plan_rank: bad arguments");
+    if (num_ranks < 1 || rank < 0 || rank >= num_ranks) YKH_THROW("invalid rank " + std::to_string(rank) + " of " + std::to_string(num_ranks));
+    RankPlan p;
+    for (int d = 0; d < ndims; d++) {
+        p.global_size[d] = plan->global_size[d];
+        p.rank_size[d] = plan->global_size[d] > 0 ? 0 : plan->local_size[d];
+        p.num_ranks[d] = plan->num_ranks[d];
+    }
+    try { plan_rank(p, ndims, num_ranks, rank, {}, false); } catch (const PlanError& e) { YKH_THROW(e.what()); }
+    for (int d = 0; d < ndims; d++) {
+        plan->global_size[d] = p.global_size[d]; plan->local_size[d] = p.local_size[d]; plan->num_ranks[d] = p.num_ranks[d];
+        plan->rank_index[d] = p.rank_index[d]; plan->rank_offset[d] = p.rank_ofs[d];
+    }
+    plan->num_neighbors = (int)p.neighbors.size();
+    for (size_t i = 0; i < p.neighbors.size() && i < 26; i++) {
+        plan->neighbor_rank[i] = p.neighbors[i].rank;
+        for (int d = 0; d < 3; d++) plan->neighbor_offset[i][d] = p.neighbors[i].ofs[d];
+    }
+    return 0;
+    YK_CATCH(1)
+}
+int yk_plan_halo_slab(int ndims, const yk_rank_plan_t* plan, const int* nofs, const yk_idx_t* hl, const yk_idx_t* hr,
+                      int l1_norm, int sending, yk_box_t* box) {
+    YK_TRY
+    if (!plan || !nofs || !hl || !hr || !box || ndims < 1 || ndims > MAX_DOMAIN_DIMS) YKH_THROW("yk_plan_halo_slab: bad arguments");
+    VarGeom g;
+    PlanNeighbor nb;
+    nb.rank = -1; nb.l1 = 0;
+    idx_t nr[3] = {1, 1, 1}, ri[3] = {0, 0, 0};
+    for (int d = 0; d < MAX_DOMAIN_DIMS; d++) {
+        g.uses_domain[d] = d < ndims;
+        g.dom_size[d] = d < ndims ? plan->local_size[d] : 1;
+        g.halo_l[d] = d < ndims ? hl[d] : 0; g.halo_r[d] = d < ndims ? hr[d] : 0;
+        nb.ofs[d] = d < ndims ? nofs[d] : 0;
+        nb.l1 += nb.ofs[d] < 0 ? -nb.ofs[d] : nb.ofs[d];
+        if (d < ndims) { nr[d] = plan->num_ranks[d]; ri[d] = plan->rank_index[d]; }
+    }
+    g.l1_norm = l1_norm;
+    idx_t lo[3], n[3];
+    if (!plan_halo_slab(ndims, nr, ri, g, nb, sending != 0, lo, n)) return 0;
+    for (int d = 0; d < 3; d++) { box->first[d] = lo[d]; box->size[d] = n[d]; }
+    return 1;
+    YK_CATCH(-1)
+}
+
 // ---- var
 const char* yk_var_get_name(yk_var_h v) { return v ? reinterpret_cast<Var*>(v)->name.c_str() : ""; }
 int yk_var_get_num_dims(yk_var_h v) { return v ? (int)reinterpret_cast<Var*>(v)->dims.size() : 0; }

@@ -22,38 +22,18 @@
 namespace ykh {
 
 static bool slab_for(const Solution& s, const Var& v, const Solution::Neighbor& nb, bool sending, Slab& out) {
-    if (v.fixed_size || v.l1_norm < nb.l1 || !v.is_allocated()) return false;
-    out.elems = 1;
+    if (v.fixed_size || !v.is_allocated()) return false;
+    VarGeom g;
     for (int d = 0; d < MAX_DOMAIN_DIMS; d++) {
-        const int o = nb.ofs[d];
-        if (d >= s.ndd || !v.uses_domain[d]) {
-            if (o != 0) return false;   // var does not extend in a dim the neighbour is offset in
-            out.lo[d] = 0; out.n[d] = 1;
-            continue;
-        }
-        const idx_t n = v.dom_size[d];
-        if (o == 0) {
-            idx_t lo = 0, hi = n;
-            if (v.l1_norm > 1) {
-                if (s.rank_index[d] == 0) lo -= v.halo_l[d];
-                if (s.rank_index[d] == s.num_ranks[d] - 1) hi += v.halo_r[d];
-            }
-            out.lo[d] = lo; out.n[d] = hi - lo;
-        } else if (sending) {
-            // to the left neighbour: my first halo_r points; to the right: my last halo_l points
-            idx_t w = (o < 0) ? v.halo_r[d] : v.halo_l[d];
-            out.lo[d] = (o < 0) ? 0 : n - w;
-            out.n[d] = w;
-        } else {
-            // from the left neighbour into my left halo; from the right into my right halo
-            idx_t w = (o < 0) ? v.halo_l[d] : v.halo_r[d];
-            out.lo[d] = (o < 0) ? -w : n;
-            out.n[d] = w;
-        }
-        if (out.n[d] <= 0) return false;
-        out.elems *= out.n[d];
+        g.uses_domain[d] = v.uses_domain[d]; g.dom_size[d] = v.dom_size[d];
+        g.halo_l[d] = v.halo_l[d]; g.halo_r[d] = v.halo_r[d];
     }
-    out.elems *= v.misc_elems;
+    g.l1_norm = v.l1_norm;
+    PlanNeighbor pn;
+    pn.rank = nb.rank; pn.l1 = nb.l1;
+    for (int d = 0; d < MAX_DOMAIN_DIMS; d++) pn.ofs[d] = nb.ofs[d];
+    if (!plan_halo_slab(s.ndd, s.num_ranks, s.rank_index, g, pn, sending, out.lo, out.n)) return false;
+    out.elems = out.n[0] * out.n[1] * out.n[2] * v.misc_elems;
     return true;
 }
 

@@ -1,0 +1,168 @@
+// ykh_plan.cpp -- domain decomposition as pure index arithmetic (no HIP calls, usable without a GPU).
+//
+// Re-statement, for one process per GPU, of the reference's rank set-up:
+//   rank grid            <- StencilContext::setup_rank (src/kernel/lib/setup.cpp:169-524),
+//                           most-compact factorisation (src/common/tuple.cpp:355-430);
+//   rank id -> coords    <- unlayout with the first domain dim varying fastest (setup.cpp:242-243);
+//   local sizes/offsets  <- ceil(global/nranks), remainder on the last rank (setup.cpp:453-495);
+//   neighbours           <- up to 3^N-1 (MPIInfo, settings.hpp:331-433);
+//   halo slabs           <- alloc_mpi_data buffer geometry (src/kernel/lib/alloc.cpp:456-859).
+// Solution::setup_rank()/alloc_halo_buffers() and the C ABI's yk_plan_* entry points share this code,
+// so the multi-process CPU tests exercise exactly what runs on the GPUs.
+#include <algorithm>
+#include <cstdlib>
+#include <sstream>
+
+#include "ykh_plan.hpp"
+
+namespace ykh {
+
+static inline idx_t ceil_div(idx_t a, idx_t b) { return (a + b - 1) / b; }
+
+// Most-compact factorisation: minimise the largest factor; candidates are visited with the factor
+// of dim 1 varying fastest and dim 0 derived (src/common/tuple.cpp:355-430), first best wins.
+void compact_factors(idx_t N, int nd, idx_t* f) {
+    idx_t given = 1;
+    bool all = true;
+    for (int d = 0; d < nd; d++) { if (f[d] > 0) given *= f[d]; else all = false; }
+    if (all && given == N) return;
+    std::vector<idx_t> facts;
+    for (idx_t n = 1; n <= N; n++) if (N % n == 0) facts.push_back(n);
+    for (int keep = 1; keep >= 0; keep--) {
+        idx_t best[MAX_DOMAIN_DIMS] = {0, 0, 0};
+        idx_t best_max = -1;
+        std::vector<size_t> ix(nd, 0);
+        while (true) {
+            idx_t can[MAX_DOMAIN_DIMS] = {1, 1, 1};
+            for (int d = 1; d < nd; d++) can[d] = (keep && f[d] > 0) ? f[d] : facts[ix[d]];
+            idx_t rest = 1;
+            for (int d = 1; d < nd; d++) rest *= can[d];
+            if (keep && f[0] > 0) can[0] = f[0];
+            else can[0] = (N % rest == 0) ? N / rest : 0;
+            idx_t prod = 1, mx = 0;
+            for (int d = 0; d < nd; d++) { prod *= can[d]; mx = std::max(mx, can[d]); }
+            if (can[0] > 0 && prod == N && (best_max < 0 || mx < best_max)) {
+                best_max = mx;
+                for (int d = 0; d < nd; d++) best[d] = can[d];
+            }
+            int d = 1;
+            for (; d < nd; d++) {
+                if (keep && f[d] > 0) continue;
+                if (++ix[d] < facts.size()) break;
+                ix[d] = 0;
+            }
+            if (d >= nd) break;
+        }
+        if (best_max >= 0) { for (int d = 0; d < nd; d++) f[d] = best[d]; return; }
+    }
+    throw PlanError("cannot factor " + std::to_string(N) + " ranks over the domain dims");
+}
+
+void plan_rank(RankPlan& p, int ndd, int nranks, int rank, const std::vector<std::string>& dim_names,
+               bool rank_index_set) {
+    idx_t f[MAX_DOMAIN_DIMS] = {1, 1, 1};
+    for (int d = 0; d < ndd; d++) f[d] = p.num_ranks[d];
+    compact_factors(nranks, ndd, f);
+    idx_t prod = 1;
+    for (int d = 0; d < ndd; d++) prod *= f[d];
+    auto dn = [&](int d) { return d < (int)dim_names.size() ? dim_names[d] : std::string(1, char('x' + d)); };
+    if (prod != nranks) {
+        std::ostringstream os;
+        os << prod << " rank(s) requested (";
+        for (int d = 0; d < ndd; d++) os << (d ? " * " : "") << dn(d) << "=" << f[d];
+        os << "), but " << nranks << " rank(s) are active";
+        throw PlanError(os.str());
+    }
+    for (int d = 0; d < ndd; d++) p.num_ranks[d] = f[d];
+    // rank id -> coords with the first domain dim varying fastest (Tuple::unlayout, first_inner)
+    if (!rank_index_set) {
+        idx_t me = rank;
+        for (int d = 0; d < ndd; d++) { p.rank_index[d] = me % p.num_ranks[d]; me /= p.num_ranks[d]; }
+    }
+    for (int d = 0; d < ndd; d++)
+        if (p.rank_index[d] < 0 || p.rank_index[d] >= p.num_ranks[d])
+            throw PlanError("rank index of " + std::to_string(p.rank_index[d]) + " is not within allowed range [0 ... " +
+                            std::to_string(p.num_ranks[d] - 1) + "] in '" + dn(d) + "' dimension on rank " + std::to_string(rank));
+    // sizes: either global or local given per dim (setup.cpp:453-495)
+    for (int d = 0; d < ndd; d++) {
+        if (p.global_size[d] > 0 && p.rank_size[d] == 0) {
+            idx_t base = ceil_div(p.global_size[d], p.num_ranks[d]);
+            idx_t last = p.global_size[d] - base * (p.num_ranks[d] - 1);
+            if (last <= 0)
+                throw PlanError("global-domain size " + std::to_string(p.global_size[d]) + " in '" + dn(d) +
+                                "' cannot be split over " + std::to_string(p.num_ranks[d]) + " ranks");
+            p.local_size[d] = (p.rank_index[d] == p.num_ranks[d] - 1) ? last : base;
+            p.rank_ofs[d] = p.rank_index[d] * base;
+        } else if (p.rank_size[d] > 0) {
+            p.local_size[d] = p.rank_size[d];
+            // every rank in a grid line must use the same size for the offsets to be derivable locally
+            p.rank_ofs[d] = p.rank_index[d] * p.rank_size[d];
+            p.global_size[d] = p.rank_size[d] * p.num_ranks[d];
+        } else {
+            throw PlanError("both local-domain size and global-domain size are zero in '" + dn(d) +
+                            "' dimension on rank " + std::to_string(rank) + "; specify one, and the other will be calculated");
+        }
+    }
+    // neighbours
+    p.neighbors.clear();
+    int nloop[3] = {ndd > 0 ? 3 : 1, ndd > 1 ? 3 : 1, ndd > 2 ? 3 : 1};
+    for (int a = 0; a < nloop[0]; a++)
+        for (int b = 0; b < nloop[1]; b++)
+            for (int c = 0; c < nloop[2]; c++) {
+                int o[3] = {nloop[0] > 1 ? a - 1 : 0, nloop[1] > 1 ? b - 1 : 0, nloop[2] > 1 ? c - 1 : 0};
+                if (!o[0] && !o[1] && !o[2]) continue;
+                idx_t co[3];
+                bool ok = true;
+                for (int d = 0; d < ndd; d++) {
+                    co[d] = p.rank_index[d] + o[d];
+                    if (co[d] < 0 || co[d] >= p.num_ranks[d]) ok = false;
+                }
+                if (!ok) continue;
+                idx_t id = 0;
+                for (int d = ndd - 1; d >= 0; d--) id = id * p.num_ranks[d] + co[d];
+                PlanNeighbor nb;
+                nb.rank = (int)id;
+                nb.l1 = 0;
+                for (int d = 0; d < MAX_DOMAIN_DIMS; d++) { nb.ofs[d] = d < ndd ? o[d] : 0; nb.l1 += std::abs(nb.ofs[d]); }
+                p.neighbors.push_back(nb);
+            }
+}
+
+// What travels between this rank and the neighbour at offset nb.ofs for one var:
+//   in each dim d with ofs[d] = -1 my first halo_r[d] domain points (they fill the neighbour's right
+//   halo), with ofs[d] = +1 my last halo_l[d] points, with ofs[d] = 0 my whole extent in d -- extended
+//   into my own halo at a *global* boundary when the var is read diagonally (l1_norm > 1), as
+//   alloc.cpp:544-553 does, so that corner cells end up identical to a single-rank run.
+bool plan_halo_slab(int ndd, const idx_t* num_ranks, const idx_t* rank_index, const VarGeom& v,
+                    const PlanNeighbor& nb, bool sending, idx_t* lo, idx_t* n) {
+    if (v.l1_norm < nb.l1) return false;
+    for (int d = 0; d < MAX_DOMAIN_DIMS; d++) {
+        const int o = nb.ofs[d];
+        if (d >= ndd || !v.uses_domain[d]) {
+            if (o != 0) return false;   // var does not extend in a dim the neighbour is offset in
+            lo[d] = 0; n[d] = 1;
+            continue;
+        }
+        const idx_t sz = v.dom_size[d];
+        if (o == 0) {
+            idx_t l = 0, h = sz;
+            if (v.l1_norm > 1) {
+                if (rank_index[d] == 0) l -= v.halo_l[d];
+                if (rank_index[d] == num_ranks[d] - 1) h += v.halo_r[d];
+            }
+            lo[d] = l; n[d] = h - l;
+        } else if (sending) {
+            idx_t w = (o < 0) ? v.halo_r[d] : v.halo_l[d];
+            lo[d] = (o < 0) ? 0 : sz - w;
+            n[d] = w;
+        } else {
+            idx_t w = (o < 0) ? v.halo_l[d] : v.halo_r[d];
+            lo[d] = (o < 0) ? -w : sz;
+            n[d] = w;
+        }
+        if (n[d] <= 0) return false;
+    }
+    return true;
+}
+
+}  // namespace ykh

@@ -1,0 +1,41 @@
+// ykh_plan.hpp -- device-free decomposition planning (see ykh_plan.cpp).
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ykh_meta.hpp"
+
+namespace ykh {
+
+struct PlanError : public std::runtime_error {
+    explicit PlanError(const std::string& m) : std::runtime_error(m) {}
+};
+
+struct PlanNeighbor { int rank; int ofs[MAX_DOMAIN_DIMS]; int l1; };
+
+struct RankPlan {
+    // in: requested sizes / grid (0 = derive); out: resolved values
+    idx_t global_size[MAX_DOMAIN_DIMS] = {0, 0, 0};
+    idx_t rank_size[MAX_DOMAIN_DIMS] = {0, 0, 0};
+    idx_t num_ranks[MAX_DOMAIN_DIMS] = {0, 0, 0};
+    idx_t rank_index[MAX_DOMAIN_DIMS] = {0, 0, 0};
+    // out
+    idx_t local_size[MAX_DOMAIN_DIMS] = {0, 0, 0};
+    idx_t rank_ofs[MAX_DOMAIN_DIMS] = {0, 0, 0};
+    std::vector<PlanNeighbor> neighbors;
+};
+
+struct VarGeom {
+    bool uses_domain[MAX_DOMAIN_DIMS];
+    idx_t dom_size[MAX_DOMAIN_DIMS];
+    idx_t halo_l[MAX_DOMAIN_DIMS], halo_r[MAX_DOMAIN_DIMS];
+    int l1_norm;
+};
+
+void compact_factors(idx_t N, int nd, idx_t* f);
+void plan_rank(RankPlan& p, int ndd, int nranks, int rank, const std::vector<std::string>& dim_names, bool rank_index_set);
+bool plan_halo_slab(int ndd, const idx_t* num_ranks, const idx_t* rank_index, const VarGeom& v,
+                    const PlanNeighbor& nb, bool sending, idx_t* lo, idx_t* n);
+
+}  // namespace ykh

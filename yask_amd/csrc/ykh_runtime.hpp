@@ -22,6 +22,7 @@
 
 #include "ykh_device.hpp"
 #include "ykh_meta.hpp"
+#include "ykh_plan.hpp"
 
 namespace ykh {
 

@@ -300,115 +300,27 @@ std::string Solution::get_command_line_values() const {
 }
 
 // ------------------------------------------------------------------ rank grid (setup.cpp:169-524)
-// Most-compact factorisation: minimise the largest factor; candidates are visited with the factor
-// of dim 1 varying fastest and dim 0 derived (src/common/tuple.cpp:355-430), first best wins.
-static void compact_factors(idx_t N, int nd, idx_t* f) {
-    idx_t given = 1;
-    bool all = true;
-    for (int d = 0; d < nd; d++) { if (f[d] > 0) given *= f[d]; else all = false; }
-    if (all && given == N) return;
-    std::vector<idx_t> facts;
-    for (idx_t n = 1; n <= N; n++) if (N % n == 0) facts.push_back(n);
-    for (int keep = 1; keep >= 0; keep--) {
-        idx_t best[MAX_DOMAIN_DIMS] = {0, 0, 0};
-        idx_t best_max = -1;
-        // iterate dims 1..nd-1 over factors (dim 1 fastest), dim 0 computed
-        std::vector<size_t> ix(nd, 0);
-        while (true) {
-            idx_t can[MAX_DOMAIN_DIMS] = {1, 1, 1};
-            for (int d = 1; d < nd; d++) can[d] = (keep && f[d] > 0) ? f[d] : facts[ix[d]];
-            idx_t rest = 1;
-            for (int d = 1; d < nd; d++) rest *= can[d];
-            if (keep && f[0] > 0) can[0] = f[0];
-            else can[0] = (N % rest == 0) ? N / rest : 0;
-            idx_t prod = 1, mx = 0;
-            for (int d = 0; d < nd; d++) { prod *= can[d]; mx = std::max(mx, can[d]); }
-            if (can[0] > 0 && prod == N && (best_max < 0 || mx < best_max)) {
-                best_max = mx;
-                for (int d = 0; d < nd; d++) best[d] = can[d];
-            }
-            int d = 1;
-            for (; d < nd; d++) {
-                if (keep && f[d] > 0) continue;
-                if (++ix[d] < facts.size()) break;
-                ix[d] = 0;
-            }
-            if (d >= nd) break;
-        }
-        if (best_max >= 0) { for (int d = 0; d < nd; d++) f[d] = best[d]; return; }
-    }
-    YKH_THROW("cannot factor " + std::to_string(N) + " ranks over the domain dims");
-}
-
+// The arithmetic lives in ykh_plan.cpp (shared with the device-free yk_plan_* C entry points).
 void Solution::setup_rank() {
-    const idx_t nr = env->nranks;
-    idx_t f[MAX_DOMAIN_DIMS] = {1, 1, 1};
-    for (int d = 0; d < ndd; d++) f[d] = num_ranks[d];
-    compact_factors(nr, ndd, f);
-    idx_t prod = 1;
-    for (int d = 0; d < ndd; d++) prod *= f[d];
-    if (prod != nr) {
-        std::ostringstream os;
-        os << prod << " rank(s) requested (";
-        for (int d = 0; d < ndd; d++) os << (d ? " * " : "") << domain_dim_names[d] << "=" << f[d];
-        os << "), but " << nr << " rank(s) are active";
-        YKH_THROW(os.str());
-    }
-    for (int d = 0; d < ndd; d++) num_ranks[d] = f[d];
-    // rank id -> coords with the first domain dim varying fastest (Tuple::unlayout, first_inner)
-    if (!rank_index_set) {
-        idx_t me = env->rank;
-        for (int d = 0; d < ndd; d++) { rank_index[d] = me % num_ranks[d]; me /= num_ranks[d]; }
-    }
-    for (int d = 0; d < ndd; d++)
-        if (rank_index[d] < 0 || rank_index[d] >= num_ranks[d])
-            YKH_THROW("rank index of " + std::to_string(rank_index[d]) + " is not within allowed range [0 ... " +
-                      std::to_string(num_ranks[d] - 1) + "] in '" + domain_dim_names[d] + "' dimension on rank " +
-                      std::to_string(env->rank));
-    // sizes: either global or local given per dim (setup.cpp:453-495)
+    RankPlan p;
     for (int d = 0; d < ndd; d++) {
-        if (global_size[d] > 0 && rank_size[d] == 0) {
-            idx_t base = ceil_div(global_size[d], num_ranks[d]);
-            idx_t last = global_size[d] - base * (num_ranks[d] - 1);
-            if (last <= 0)
-                YKH_THROW("global-domain size " + std::to_string(global_size[d]) + " in '" + domain_dim_names[d] +
-                          "' cannot be split over " + std::to_string(num_ranks[d]) + " ranks");
-            local_size[d] = (rank_index[d] == num_ranks[d] - 1) ? last : base;
-            rank_ofs[d] = rank_index[d] * base;
-        } else if (rank_size[d] > 0) {
-            local_size[d] = rank_size[d];
-            // every rank in a grid line must use the same size for the offsets to be derivable locally
-            rank_ofs[d] = rank_index[d] * rank_size[d];
-            global_size[d] = rank_size[d] * num_ranks[d];
-        } else {
-            YKH_THROW("both local-domain size and global-domain size are zero in '" + domain_dim_names[d] +
-                      "' dimension on rank " + std::to_string(env->rank) +
-                      "; specify one, and the other will be calculated");
-        }
+        p.global_size[d] = global_size[d]; p.rank_size[d] = rank_size[d];
+        p.num_ranks[d] = num_ranks[d]; p.rank_index[d] = rank_index[d];
     }
-    // neighbours
+    try {
+        plan_rank(p, ndd, env->nranks, env->rank, domain_dim_names, rank_index_set);
+    } catch (const PlanError& e) { YKH_THROW(e.what()); }
     neighbors.clear();
-    int nloop[3] = {ndd > 0 ? 3 : 1, ndd > 1 ? 3 : 1, ndd > 2 ? 3 : 1};
-    for (int a = 0; a < nloop[0]; a++)
-        for (int b = 0; b < nloop[1]; b++)
-            for (int c = 0; c < nloop[2]; c++) {
-                int o[3] = {nloop[0] > 1 ? a - 1 : 0, nloop[1] > 1 ? b - 1 : 0, nloop[2] > 1 ? c - 1 : 0};
-                if (!o[0] && !o[1] && !o[2]) continue;
-                idx_t co[3];
-                bool ok = true;
-                for (int d = 0; d < ndd; d++) {
-                    co[d] = rank_index[d] + o[d];
-                    if (co[d] < 0 || co[d] >= num_ranks[d]) ok = false;
-                }
-                if (!ok) continue;
-                idx_t id = 0;
-                for (int d = ndd - 1; d >= 0; d--) id = id * num_ranks[d] + co[d];
-                Neighbor nb;
-                nb.rank = (int)id;
-                nb.l1 = 0;
-                for (int d = 0; d < MAX_DOMAIN_DIMS; d++) { nb.ofs[d] = d < ndd ? o[d] : 0; nb.l1 += std::abs(nb.ofs[d]); }
-                neighbors.push_back(nb);
-            }
+    for (int d = 0; d < ndd; d++) {
+        global_size[d] = p.global_size[d]; num_ranks[d] = p.num_ranks[d]; rank_index[d] = p.rank_index[d];
+        local_size[d] = p.local_size[d]; rank_ofs[d] = p.rank_ofs[d];
+    }
+    for (auto& pn : p.neighbors) {
+        Neighbor nb;
+        nb.rank = pn.rank; nb.l1 = pn.l1;
+        for (int d = 0; d < MAX_DOMAIN_DIMS; d++) nb.ofs[d] = pn.ofs[d];
+        neighbors.push_back(nb);
+    }
 }
 
 // ------------------------------------------------------------------ prepare / end
