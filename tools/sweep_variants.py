@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--bytes-per-point", type=float, default=16.0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--part", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=0, help="also time N whole steps with the default variants")
     args = ap.parse_args()
     from yask_amd import yk_factory
     from oracle import oracle as O
@@ -46,14 +48,14 @@ def main():
             v.set_elements_hash(off, sc, hash_id=O.VAR_IDS[args.stencil][v.get_name()])
         ref.run_solution(0, 1)
     pts = float(size[0]) * size[1] * size[2]
-    names = soln.get_kernel_variant_names(0)
+    names = soln.get_kernel_variant_names(args.part)
     results = []
     for vi, name in enumerate(names):
         chunks = args.chunks if name != "naive" else [0]
         for xc in chunks:
             try:
-                soln.time_part(0, vi, xc, 0, 2)
-                ms = soln.time_part(0, vi, xc, 0, args.reps)
+                soln.time_part(args.part, vi, xc, 0, 2)
+                ms = soln.time_part(args.part, vi, xc, 0, args.reps)
             except RuntimeError as e:
                 print("FAILED", name, xc, e, flush=True)
                 continue
@@ -74,8 +76,18 @@ def main():
             print("check", name, "mismatches vs naive:", bad, flush=True)
             results.append({"variant": name, "mismatches_vs_naive": bad})
             chk.end_solution()
+    if args.steps > 0:
+        soln.run_solution(0, 1)
+        soln.get_stats()
+        soln.run_solution(2, 1 + args.steps)
+        st = soln.get_stats()
+        rec = {"whole_step_ms": round(st.get_elapsed_secs() / args.steps * 1e3, 4),
+               "gpoints_per_s": round(pts * args.steps / st.get_elapsed_secs() * 1e-9, 2),
+               "variants": [soln.get_kernel_variant(i) for i in range(8) if i < soln.get_num_parts()]}
+        results.append(rec)
+        print("WHOLE STEP:", rec, flush=True)
     results_sorted = sorted([r for r in results if "ms" in r], key=lambda r: r["ms"])
-    out = args.out or str(ROOT / "gpurun_out" / f"sweep_{args.stencil}_{size[0]}x{size[1]}x{size[2]}.json")
+    out = args.out or str(ROOT / "gpurun_out" / f"sweep_{args.stencil}_p{args.part}_{size[0]}x{size[1]}x{size[2]}.json")
     Path(out).parent.mkdir(parents=True, exist_ok=True)
     json.dump({"size": size, "results": results, "best": results_sorted[:5]}, open(out, "w"), indent=1)
     print("BEST:", results_sorted[:5])

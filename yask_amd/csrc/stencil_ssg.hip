@@ -14,14 +14,24 @@ const SolnImpl& ykh_solution_impl() {
             PartImpl p;
             p.meta = &parts[0];
             p.variants.push_back(naive_variant<part_1>());
-            p.default_variant = 0;
+            p.variants.push_back(vecpt_variant<part_1, 4, 64, 4, 1>());
+            p.variants.push_back(vecpt_variant<part_1, 4, 64, 4, 2>());
+            p.variants.push_back(vecpt_variant<part_1, 4, 32, 8, 2>());
+            p.variants.push_back(vecpt_variant<part_1, 4, 64, 4, 4>());
+            p.variants.push_back(vecpt_variant<part_1, 2, 64, 4, 2>());
+            p.set_default("vecpt_v4_z256_y4_x2");
             s.parts.push_back(p);
         }
         {
             PartImpl p;
             p.meta = &parts[1];
             p.variants.push_back(naive_variant<part_2>());
-            p.default_variant = 0;
+            p.variants.push_back(vecpt_variant<part_2, 4, 64, 4, 1>());
+            p.variants.push_back(vecpt_variant<part_2, 4, 64, 4, 2>());
+            p.variants.push_back(vecpt_variant<part_2, 4, 32, 8, 2>());
+            p.variants.push_back(vecpt_variant<part_2, 4, 64, 4, 4>());
+            p.variants.push_back(vecpt_variant<part_2, 2, 64, 4, 2>());
+            p.set_default("vecpt_v4_z256_y4_x2");
             s.parts.push_back(p);
         }
         return s;

@@ -47,6 +47,7 @@ struct KernelVariant {
     int threads;
     void (*launch)(const PartArgs& a, dim3 grid, hipStream_t s);
     int vz = 0;            // elements per thread along z (0: one 16-byte vector)
+    int rx = 0;            // >0: not a marching kernel; a block handles rx consecutive x planes (vecpt)
 };
 struct PartImpl {
     const PartMeta* meta;

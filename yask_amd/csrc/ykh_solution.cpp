@@ -443,6 +443,15 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
         a.ntz = (int)ceil_div(box.hi[2] - zt0, kv.tz);
         a.nty = (int)ceil_div(box.hi[1] - box.lo[1], kv.ty);
         idx_t nx = box.hi[0] - box.lo[0];
+        if (kv.rx > 0) {
+            // point kernel: grid = z tiles * y tiles * x blocks
+            a.nxc = (int)ceil_div(nx, kv.rx);
+            a.xchunk = kv.rx;
+            dim3 grid((unsigned)((idx_t)a.ntz * a.nty * a.nxc), 1, 1);
+            kv.launch(a, grid, s);
+            YKH_HIP(hipGetLastError());
+            return;
+        }
         idx_t xc = xchunk;
         if (xc <= 0) {
             // default: march the whole box unless that leaves the chip short of workgroups

@@ -6,6 +6,7 @@
 
 #include "ykh_device.hpp"
 #include "ykh_starlin.hpp"
+#include "ykh_vecpt.hpp"
 #include "ykh_runtime.hpp"
 
 namespace ykh {
@@ -54,6 +55,21 @@ void launch_starlin(const PartArgs& a, dim3 grid, hipStream_t s) {
         attr_set = true;
     }
     hipLaunchKernelGGL((starlin_kernel<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL>), grid, dim3(C::NT), C::lds_bytes, s, a);
+}
+
+template <class P, int VZ, int TZL, int TYL, int RX>
+void launch_vecpt(const PartArgs& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((vecpt_kernel<P, VZ, TZL, TYL, RX>), grid, dim3(TZL * TYL), 0, s, a);
+}
+// Generic vector-per-thread kernel (ykh_vecpt.hpp). Name: vecpt_v<VZ>_z<tile z>_y<tile y>_x<planes per thread>
+template <class P, int VZ, int TZL, int TYL, int RX>
+KernelVariant vecpt_variant() {
+    static const std::string name = "vecpt_v" + std::to_string(VZ) + "_z" + std::to_string(TZL * VZ) + "_y" +
+                                    std::to_string(TYL) + "_x" + std::to_string(RX);
+    KernelVariant kv{name.c_str(), true, TZL * VZ, TYL, 0, TZL * TYL, &launch_vecpt<P, VZ, TZL, TYL, RX>};
+    kv.vz = VZ;
+    kv.rx = RX;
+    return kv;
 }
 
 // Linear-star-form kernel (ykh_starlin.hpp); only for parts with P::has_lin.

@@ -323,6 +323,17 @@ class yk_solution:
         return self._lib.call("yk_solution_compare_data", self._h, ref._h, float(epsilon))
     def set_streams(self, compute_stream, comm_stream):
         self._lib.call_rc("yk_solution_set_streams", self._h, C.c_void_p(compute_stream), C.c_void_p(comm_stream))
+    def get_num_parts(self):
+        n = 0
+        while True:
+            try:
+                if self._lib.c.yk_solution_get_num_kernel_variants(self._h, n) <= 0:
+                    self._lib.c.yk_clear_error()
+                    return n
+            except Exception:
+                return n
+            n += 1
+
     def get_kernel_variant(self, part=0): return self._lib.call("yk_solution_get_kernel_variant", self._h, part).decode()
     def get_kernel_variant_names(self, part=0):
         n = self._lib.call("yk_solution_get_num_kernel_variants", self._h, part)
