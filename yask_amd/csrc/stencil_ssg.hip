@@ -5,6 +5,9 @@
 #include "ykh_stencil_tu.hpp"
 
 namespace ykh {
+void ssg_variants_k1(PartImpl&);   // marching kernels, stage 1
+void ssg_variants_k2(PartImpl&);   // marching kernels, stage 2
+
 const SolnImpl& ykh_solution_impl() {
     using namespace ykh_gen_ssg;
     static const SolnImpl impl = [] {
@@ -19,7 +22,8 @@ const SolnImpl& ykh_solution_impl() {
             p.variants.push_back(vecpt_variant<part_1, 4, 32, 8, 2>());
             p.variants.push_back(vecpt_variant<part_1, 4, 64, 4, 4>());
             p.variants.push_back(vecpt_variant<part_1, 2, 64, 4, 2>());
-            p.set_default("vecpt_v4_z256_y4_x2");
+            ssg_variants_k1(p);
+            p.set_default("march_v2_z128_y8_w2");
             s.parts.push_back(p);
         }
         {
@@ -31,7 +35,8 @@ const SolnImpl& ykh_solution_impl() {
             p.variants.push_back(vecpt_variant<part_2, 4, 32, 8, 2>());
             p.variants.push_back(vecpt_variant<part_2, 4, 64, 4, 4>());
             p.variants.push_back(vecpt_variant<part_2, 2, 64, 4, 2>());
-            p.set_default("vecpt_v4_z256_y4_x2");
+            ssg_variants_k2(p);
+            p.set_default("march_v2_z128_y8_w2");
             s.parts.push_back(p);
         }
         return s;

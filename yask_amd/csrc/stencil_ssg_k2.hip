@@ -1,0 +1,13 @@
+// stencil_ssg_k2.hip -- marching-kernel tile shapes for ssg part_2.
+#include "gen/ssg_cdna4_hip.hpp"
+#include "ykh_stencil_tu.hpp"
+namespace ykh {
+using namespace ykh_gen_ssg;
+void ssg_variants_k2(PartImpl& p) {
+    p.variants.push_back(march_variant<part_2, 4, 32, 16, 2>());
+    p.variants.push_back(march_variant<part_2, 4, 32, 8, 2>());
+    p.variants.push_back(march_variant<part_2, 2, 64, 8, 2>());
+    p.variants.push_back(march_variant<part_2, 2, 32, 16, 2>());
+    p.variants.push_back(march_variant<part_2, 2, 64, 4, 2>());
+}
+}  // namespace ykh

@@ -1,0 +1,292 @@
+// ykh_march.hpp -- generic 2.5-D marching kernel for multi-var / multi-equation parts (ssg).
+//
+// Generalises star25d (ykh_device.hpp) from one star group to every access group of a part.  The
+// generated part is analysed at compile time, per (var, step) group g:
+//   * x-neighbours   -> a register queue of the planes x+xlo_g .. x+xhi_g at the thread's own point
+//                       (depth 1 for centre-only operands: a one-plane prefetch register);
+//   * y/z-neighbours -> an LDS slab of the centre plane of g with exactly g's halo (y-only and z-only
+//                       groups get row/column halos only), double buffered, one barrier per plane;
+//                       the slab interior is written from the queue's centre entry, the halo from
+//                       per-thread prefetch registers;
+//   * mixed offsets  -> (rare: ssg's `mu`) direct aligned global loads, as in ykh_vecpt.hpp.
+// A workgroup owns a (y,z) tile and marches along x, so x re-use lives in registers and never depends
+// on cache capacity: the point kernels re-fetch every x-neighbour plane over the fabric
+// (ssg stage 1: ~124 B/point moved for 52 B/point algorithmic), this kernel moves each plane once
+// (+ tile halos).  All loads are 16-byte vectors along z, a wave covers whole tile rows.
+// Replaces the reference's generated calc_vectors loop + block loops for such parts
+// (src/compiler/lib/YaskKernel.cpp:591-719, src/kernel/lib/stencil_calc.cpp:40-289).
+#pragma once
+#include "ykh_device.hpp"
+#include "ykh_starlin.hpp"   // vecn, zshiftn, ldv/stv, nt variants
+
+namespace ykh {
+
+struct GroupShape {
+    int xlo, xhi, ylo, yhi, zlo, zhi;   // ranges over axis-aligned reads
+    bool any, mixed, written;
+};
+
+template <class P>
+constexpr GroupShape group_shape(int g) {
+    GroupShape s = {0, 0, 0, 0, 0, 0, false, false, false};
+    for (int i = 0; i < P::n_reads; i++) {
+        if (P::reads[i].g != g) continue;
+        s.any = true;
+        int dx = P::reads[i].dx, dy = P::reads[i].dy, dz = P::reads[i].dz;
+        if ((dx != 0) + (dy != 0) + (dz != 0) > 1) { s.mixed = true; continue; }
+        if (dx < s.xlo) s.xlo = dx;
+        if (dx > s.xhi) s.xhi = dx;
+        if (dy < s.ylo) s.ylo = dy;
+        if (dy > s.yhi) s.yhi = dy;
+        if (dz < s.zlo) s.zlo = dz;
+        if (dz > s.zhi) s.zhi = dz;
+    }
+    for (int i = 0; i < P::n_writes; i++)
+        if (P::writes[i] == g) s.written = true;
+    return s;
+}
+
+// Per-group layout tables, computed once per instantiation at compile time (always used through
+// constexpr values: a call in a runtime context would put the analysis loops into the kernel).
+struct MarchTab {
+    int nq[MAX_GROUPS], qoff[MAX_GROUPS + 1], xlo[MAX_GROUPS];
+    bool slab[MAX_GROUPS];
+    int yl[MAX_GROUPS], yh[MAX_GROUPS], zlv[MAX_GROUPS], zhv[MAX_GROUPS], lp[MAX_GROUPS], lrows[MAX_GROUPS];
+    int soff[MAX_GROUPS + 1];
+    int nhy[MAX_GROUPS], nh[MAX_GROUPS], nht[MAX_GROUPS], hoff[MAX_GROUPS + 1];
+};
+
+template <class P, int VZ_, int TZL_, int TYL_>
+struct MarchCfg {
+    typedef typename P::real_t T;
+    static constexpr int VZ = VZ_, TZL = TZL_, TYL = TYL_, NT = TZL_ * TYL_, NG = P::n_groups;
+    static constexpr int TZ = TZL * VZ, TY = TYL;
+    static constexpr MarchTab make() {
+        MarchTab t = {};
+        int qo = 0, so = 0, ho = 0;
+        for (int g = 0; g < NG; g++) {
+            GroupShape s = group_shape<P>(g);
+            t.xlo[g] = s.xlo;
+            t.nq[g] = s.any ? s.xhi - s.xlo + 1 : 0;       // queue: planes x+xlo .. x+xhi
+            t.qoff[g] = qo; qo += t.nq[g];
+            t.slab[g] = s.any && (s.ylo || s.yhi || s.zlo || s.zhi);
+            t.yl[g] = -s.ylo; t.yh[g] = s.yhi;
+            t.zlv[g] = (-s.zlo + VZ - 1) / VZ; t.zhv[g] = (s.zhi + VZ - 1) / VZ;
+            t.lp[g] = TZ + (t.zlv[g] + t.zhv[g]) * VZ;
+            t.lrows[g] = TY + t.yl[g] + t.yh[g];
+            t.soff[g] = so; so += t.slab[g] ? t.lrows[g] * t.lp[g] : 0;
+            t.nhy[g] = (t.yl[g] + t.yh[g]) * TZL;
+            t.nh[g] = t.slab[g] ? t.nhy[g] + TY * (t.zlv[g] + t.zhv[g]) : 0;
+            t.nht[g] = (t.nh[g] + NT - 1) / NT;
+            t.hoff[g] = ho; ho += t.nht[g];
+        }
+        t.qoff[NG] = qo; t.soff[NG] = so; t.hoff[NG] = ho;
+        return t;
+    }
+    static constexpr MarchTab tab = make();
+    static constexpr int NQTOT = tab.qoff[NG];
+    static constexpr int SLAB_TOT = tab.soff[NG];           // elements of one buffer set
+    static constexpr int NHTOT = tab.hoff[NG];
+    static constexpr size_t lds_bytes = sizeof(T) * 2 * (SLAB_TOT > 0 ? SLAB_TOT : 1);
+};
+
+template <class C, class P>
+struct MarchAcc {
+    typedef typename C::T T;
+    typedef typename vecn<T, C::VZ>::type V;
+    static constexpr int VZ = C::VZ;
+    const PartArgs& a;
+    const V (&q)[C::NQTOT > 0 ? C::NQTOT : 1];
+    const T* sb;            // current slab buffer set
+    int ly, lz;             // thread position in the tile
+    int x, y, z0;           // point (first of the VZ)
+    V (&out)[MAX_GROUPS];
+    template <int G, int DX, int DY, int DZ>
+    __device__ __forceinline__ V rd() const {
+        constexpr int nz = (DX != 0) + (DY != 0) + (DZ != 0);
+        if constexpr (nz > 1) {
+            // mixed offset: aligned global loads (L1/L2 served)
+            const T* p = (const T*)a.ptr[G] + (idx_t)(x + DX) * a.gsx[G] + (idx_t)(y + DY) * a.gsy[G];
+            constexpr int qq = (DZ >= 0) ? DZ / VZ : -((-DZ + VZ - 1) / VZ);
+            constexpr int e = DZ - qq * VZ;
+            const T* pz = p + z0 + qq * VZ;
+            if constexpr (e == 0) return ldv<V>(pz);
+            else return zshiftn<T, VZ, e>(ldv<V>(pz), ldv<V>(pz + VZ));
+        } else if constexpr (DY == 0 && DZ == 0) {
+            constexpr int qi = C::tab.qoff[G] + DX - C::tab.xlo[G];
+            return q[qi];
+        } else {
+            constexpr int so = C::tab.soff[G], yl = C::tab.yl[G], lp = C::tab.lp[G], zlv = C::tab.zlv[G];
+            const T* row = sb + so + (yl + ly + DY) * lp + (zlv + lz) * VZ;
+            if constexpr (DZ == 0) return ldv<V>(row);
+            else {
+                constexpr int qq = (DZ >= 0) ? DZ / VZ : -((-DZ + VZ - 1) / VZ);
+                constexpr int e = DZ - qq * VZ;
+                if constexpr (e == 0) return ldv<V>(row + qq * VZ);
+                else return zshiftn<T, VZ, e>(ldv<V>(row + qq * VZ), ldv<V>(row + (qq + 1) * VZ));
+            }
+        }
+    }
+    // The empty asm keeps the equations of a part sequential: without it hipcc hoists the LDS/global
+    // reads of all equations to the top of eval() and the live values exceed the register file.
+    template <int G>
+    __device__ __forceinline__ void wr(V v) { out[G] = v; asm volatile("" : "+v"(out[G]) : : "memory"); }
+    template <int D>
+    __device__ __forceinline__ V idx() const {
+        if constexpr (D == 2) { V r; static_for<VZ>([&](auto ec) { constexpr int e = decltype(ec)::value; r[e] = T(z0 + e + a.ofs_z); }); return r; }
+        else return V(T(D == 0 ? x + a.ofs_x : y + a.ofs_y));
+    }
+    __device__ __forceinline__ V step() const { return V(T(a.t)); }
+};
+
+template <class P, int VZ, int TZL, int TYL, int MINW>
+__global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a) {
+    typedef MarchCfg<P, VZ, TZL, TYL> C;
+    typedef typename C::T T;
+    typedef typename vecn<T, VZ>::type V;
+    constexpr int NG = C::NG, NT = C::NT;
+    static_assert(NG <= MAX_GROUPS, "too many access groups");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char ykh_smem[];
+    T* slab = reinterpret_cast<T*>(ykh_smem);
+
+    const int ntiles = a.ntz * a.nty * a.nxc;
+    int bid = blockIdx.x;
+    if ((ntiles & 7) == 0) bid = (bid & 7) * (ntiles >> 3) + (bid >> 3);
+    const int tz_i = bid % a.ntz;
+    const int ty_i = (bid / a.ntz) % a.nty;
+    const int xc_i = bid / (a.ntz * a.nty);
+    const int tid = threadIdx.x;
+    const int lz = tid % TZL, ly = tid / TZL;
+    const int zt0 = (a.z0 & ~(VZ - 1)) + tz_i * C::TZ;
+    const int yt0 = a.y0 + ty_i * C::TY;
+    const int xs = a.x0 + xc_i * a.xchunk;
+    const int xe = (xs + a.xchunk < a.x1) ? xs + a.xchunk : a.x1;
+    if (xs >= xe) return;
+    const int myz = zt0 + lz * VZ;
+    const int myy = yt0 + ly;
+
+    // own-point offset within a plane, per group (vars lacking a dim have stride 0), clamped into the allocation
+    const int yc = clampi(myy, a.ay0, a.ay1 - 1), zc = clampi(myz, a.az0, a.az1 - VZ);
+    auto xclamp = [&](int x) { return clampi(x, a.ax0, a.ax1 - 1); };
+
+    // halo assignments: for group g, halo vector h = tid + k*NT
+    int hofs[C::NHTOT > 0 ? C::NHTOT : 1];       // (y,z) part of the global offset (gsz is 1 for slab groups)
+    int hlds[C::NHTOT > 0 ? C::NHTOT : 1];
+    static_for<NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr bool slabg = C::tab.slab[g];
+        if constexpr (slabg) {
+            constexpr int YL = C::tab.yl[g], ZLV = C::tab.zlv[g], ZHV = C::tab.zhv[g], LP = C::tab.lp[g];
+            constexpr int NHY = C::tab.nhy[g], NH = C::tab.nh[g], NHT = C::tab.nht[g], HO = C::tab.hoff[g], SO = C::tab.soff[g];
+            constexpr int ZV2 = (ZLV + ZHV > 0) ? ZLV + ZHV : 1;
+            static_for<NHT>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                int h = tid + k * NT;
+                int row, zv;
+                if (h < NHY) {
+                    int r = h / TZL;
+                    row = r < YL ? r : r + C::TY;
+                    zv = ZLV + h % TZL;
+                } else {
+                    int hh = h - NHY;
+                    int r = hh / ZV2, c = hh % ZV2;
+                    row = YL + r;
+                    zv = c < ZLV ? c : c + TZL;
+                }
+                if (h >= NH) { row = 0; zv = 0; }
+                int y = clampi(yt0 - YL + row, a.ay0, a.ay1 - 1);
+                int z = clampi(zt0 - ZLV * VZ + zv * VZ, a.az0, a.az1 - VZ);
+                hofs[HO + k] = y * (int)a.gsy[g] + z;
+                hlds[HO + k] = (h < NH) ? SO + row * LP + zv * VZ : -1;
+            });
+        }
+    });
+
+    V q[C::NQTOT > 0 ? C::NQTOT : 1];
+    V nxt[NG];
+    V hreg[C::NHTOT > 0 ? C::NHTOT : 1];
+
+    // load the own-point vector of group g at plane x (vars without z: broadcast)
+    auto ld_own = [&](auto gc, int x) -> V {
+        constexpr int g = decltype(gc)::value;
+        const T* p = (const T*)a.ptr[g] + (idx_t)xclamp(x) * a.gsx[g] + (idx_t)yc * a.gsy[g];
+        if (a.gsz[g] == 0) return V(p[0]);
+        return ldv<V>(p + zc);
+    };
+    auto prefetch = [&](int x) {      // everything needed to advance to centre plane x
+        static_for<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int NQ = C::tab.nq[g], XHI = C::tab.xlo[g] + C::tab.nq[g] - 1;
+            constexpr bool slabg = C::tab.slab[g];
+            if constexpr (NQ > 0) nxt[g] = ld_own(gc, x + XHI);
+            if constexpr (slabg) {
+                constexpr int NHT = C::tab.nht[g], HO = C::tab.hoff[g];
+                const T* p = (const T*)a.ptr[g] + (idx_t)xclamp(x) * a.gsx[g];
+                static_for<NHT>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    hreg[HO + k] = ldv<V>(p + hofs[HO + k]);
+                });
+            }
+        });
+    };
+
+    // prologue: queues hold planes xs+xlo .. xs+xhi-1; newest plane + halos of plane xs prefetched
+    static_for<NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int NQ = C::tab.nq[g], QO = C::tab.qoff[g], XLO = C::tab.xlo[g];
+        static_for<(NQ > 0 ? NQ - 1 : 0)>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            q[QO + i] = ld_own(gc, xs + XLO + i);
+        });
+    });
+    prefetch(xs);
+
+    for (int x = xs; x < xe; x++) {
+        T* sb = slab + (x & 1) * C::SLAB_TOT;
+        static_for<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int NQ = C::tab.nq[g], QO = C::tab.qoff[g], XLO = C::tab.xlo[g];
+            constexpr bool slabg = C::tab.slab[g];
+            if constexpr (NQ > 0) q[QO + NQ - 1] = nxt[g];
+            if constexpr (slabg) {
+                constexpr int YL = C::tab.yl[g], ZLV = C::tab.zlv[g], LP = C::tab.lp[g], SO = C::tab.soff[g];
+                constexpr int NHT = C::tab.nht[g], HO = C::tab.hoff[g];
+                stv<V>(sb + SO + (YL + ly) * LP + (ZLV + lz) * VZ, q[QO - XLO]);
+                static_for<NHT>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    if (hlds[HO + k] >= 0) stv<V>(sb + hlds[HO + k], hreg[HO + k]);
+                });
+            }
+        });
+        if (x + 1 < xe) prefetch(x + 1);
+        __syncthreads();
+
+        V out[MAX_GROUPS];
+        MarchAcc<C, P> acc{a, q, sb, ly, lz, x, myy, myz, out};
+        P::eval(acc);
+        if (myy < a.y1 && myz < a.z1 && myz + VZ > a.z0) {
+            static_for<P::n_writes>([&](auto wc) {
+                constexpr int g = P::writes[decltype(wc)::value];
+                T* op = (T*)a.ptr[g] + (idx_t)x * a.gsx[g] + (idx_t)myy * a.gsy[g] + myz;
+                if (myz >= a.z0 && myz + VZ <= a.z1) stv<V>(op, out[g]);
+                else
+                    static_for<VZ>([&](auto ec) {
+                        constexpr int e = decltype(ec)::value;
+                        if (myz + e >= a.z0 && myz + e < a.z1) op[e] = out[g][e];
+                    });
+            });
+        }
+        // rotate the queues
+        static_for<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int NQ = C::tab.nq[g], QO = C::tab.qoff[g];
+            static_for<(NQ > 0 ? NQ - 1 : 0)>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                q[QO + i] = q[QO + i + 1];
+            });
+        });
+    }
+}
+
+}  // namespace ykh

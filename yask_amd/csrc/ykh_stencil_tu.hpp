@@ -7,6 +7,7 @@
 #include "ykh_device.hpp"
 #include "ykh_starlin.hpp"
 #include "ykh_vecpt.hpp"
+#include "ykh_march.hpp"
 #include "ykh_runtime.hpp"
 
 namespace ykh {
@@ -69,6 +70,29 @@ KernelVariant vecpt_variant() {
     KernelVariant kv{name.c_str(), true, TZL * VZ, TYL, 0, TZL * TYL, &launch_vecpt<P, VZ, TZL, TYL, RX>};
     kv.vz = VZ;
     kv.rx = RX;
+    return kv;
+}
+
+template <class P, int VZ, int TZL, int TYL, int MINW>
+void launch_march(const PartArgs& a, dim3 grid, hipStream_t s) {
+    typedef MarchCfg<P, VZ, TZL, TYL> C;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&march_kernel<P, VZ, TZL, TYL, MINW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((march_kernel<P, VZ, TZL, TYL, MINW>), grid, dim3(C::NT), C::lds_bytes, s, a);
+}
+// Generic marching kernel (ykh_march.hpp). Name: march_v<VZ>_z<tile z>_y<tile y>_w<min waves/SIMD>
+template <class P, int VZ, int TZL, int TYL, int MINW>
+KernelVariant march_variant() {
+    typedef MarchCfg<P, VZ, TZL, TYL> C;
+    static_assert(C::lds_bytes <= 160 * 1024, "march tile does not fit the 160 KiB LDS");
+    static const std::string name = "march_v" + std::to_string(VZ) + "_z" + std::to_string(C::TZ) + "_y" +
+                                    std::to_string(C::TY) + "_w" + std::to_string(MINW);
+    KernelVariant kv{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_march<P, VZ, TZL, TYL, MINW>};
+    kv.vz = VZ;
     return kv;
 }
 
