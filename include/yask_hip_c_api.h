@@ -147,9 +147,14 @@ typedef struct {                                                             /* 
     double points_per_sec;       /* "throughput (num-points/sec)", soln_apis.cpp:455-461 */
 } yk_stats_t;
 int yk_solution_get_stats(yk_soln_h s, yk_stats_t* out);                     /* get_stats, :819 (clears the counters) */
+int yk_solution_clear_stats(yk_soln_h s);                                    /* clear_stats, :824 */
 int yk_solution_reset_auto_tuner(yk_soln_h s, int enable, int verbose);      /* :838 */
 int yk_solution_is_auto_tuner_enabled(yk_soln_h s);                          /* :855 */
 int yk_solution_run_auto_tuner_now(yk_soln_h s, int verbose);                /* :880 */
+int yk_solution_set_min_pad_size(yk_soln_h s, const char* dim, yk_idx_t n);  /* :927 */
+yk_idx_t yk_solution_get_min_pad_size(yk_soln_h s, const char* dim);         /* :941 */
+int yk_solution_set_step_wrap(yk_soln_h s, int do_wrap);                     /* set_step_wrap, :1212 */
+int yk_solution_get_step_wrap(yk_soln_h s);                                  /* get_step_wrap, :1220 */
 yk_var_h yk_solution_new_var(yk_soln_h s, const char* name, int ndims, const char* const* dims);      /* :994 */
 yk_var_h yk_solution_new_fixed_size_var(yk_soln_h s, const char* name, int ndims, const char* const* dims,
                                         const yk_idx_t* sizes);                                      /* :1069 */
@@ -210,6 +215,9 @@ yk_idx_t yk_var_set_elements_in_slice_f64(yk_var_h v, const double* buf, size_t 
                                           const yk_idx_t* first, const yk_idx_t* last);                /* :905 */
 yk_idx_t yk_var_set_elements_in_slice_same(yk_var_h v, double val, const yk_idx_t* first,
                                            const yk_idx_t* last, int strict_indices);                  /* :820 */
+/* set_elements_in_slice(source var, first source, first target, last target), yk_var_api.hpp:936 */
+yk_idx_t yk_var_set_elements_in_slice_from_var(yk_var_h v, yk_var_h source, const yk_idx_t* first_source,
+                                               const yk_idx_t* first_target, const yk_idx_t* last_target);
 int yk_var_set_all_elements_same(yk_var_h v, double val);                                             /* :800 */
 typedef struct {                                                             /* yk_var::yk_reduction_result, :960-1030 */
     int reduction_mask;

@@ -55,6 +55,12 @@ class Box(C.Structure):
 
 
 PROTOTYPES = {
+    "yk_solution_clear_stats": (C.c_int, [_H]),
+    "yk_solution_set_min_pad_size": (C.c_int, [_H, _S, idx_t]),
+    "yk_solution_get_min_pad_size": (idx_t, [_H, _S]),
+    "yk_solution_set_step_wrap": (C.c_int, [_H, C.c_int]),
+    "yk_solution_get_step_wrap": (C.c_int, [_H]),
+    "yk_var_set_elements_in_slice_from_var": (idx_t, [_H, _H, C.POINTER(idx_t), C.POINTER(idx_t), C.POINTER(idx_t)]),
     "yk_plan_rank": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(RankPlan)]),
     "yk_plan_halo_slab": (C.c_int, [C.c_int, C.POINTER(RankPlan), C.POINTER(C.c_int), C.POINTER(idx_t), C.POINTER(idx_t),
                                     C.c_int, C.c_int, C.POINTER(Box)]),

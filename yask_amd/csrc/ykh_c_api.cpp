@@ -251,6 +251,15 @@ int yk_solution_get_stats(yk_soln_h s, yk_stats_t* out) {
     return 0;
     YK_CATCH(1)
 }
+int yk_solution_clear_stats(yk_soln_h s) { YK_TRY (void)S(s).get_stats(); return 0; YK_CATCH(1) }
+int yk_solution_set_min_pad_size(yk_soln_h s, const char* dim, yk_idx_t n) {
+    YK_TRY Solution& so = S(s); so.min_pad[so.domain_dim_idx(dim, "set_min_pad_size")] = n; so.invalidate(); return 0; YK_CATCH(1)
+}
+yk_idx_t yk_solution_get_min_pad_size(yk_soln_h s, const char* dim) {
+    YK_TRY Solution& so = S(s); return so.min_pad[so.domain_dim_idx(dim, "get_min_pad_size")]; YK_CATCH(0)
+}
+int yk_solution_set_step_wrap(yk_soln_h s, int w) { YK_TRY S(s).step_wrap = (w != 0); return 0; YK_CATCH(1) }
+int yk_solution_get_step_wrap(yk_soln_h s) { return s && s->soln->step_wrap ? 1 : 0; }
 int yk_solution_reset_auto_tuner(yk_soln_h s, int enable, int) { YK_TRY S(s).reset_auto_tuner(enable != 0); return 0; YK_CATCH(1) }
 int yk_solution_is_auto_tuner_enabled(yk_soln_h s) { return s && s->soln->auto_tune ? 1 : 0; }
 int yk_solution_run_auto_tuner_now(yk_soln_h s, int verbose) {
@@ -510,6 +519,20 @@ yk_idx_t yk_var_set_elements_in_slice_f64(yk_var_h v, const double* buf, size_t 
 }
 yk_idx_t yk_var_set_elements_in_slice_same(yk_var_h v, double val, const yk_idx_t* f, const yk_idx_t* l, int strict) {
     YK_TRY Var* x = V(v); return x->set_elements_in_slice_same(val, vec(x, f), vec(x, l), strict != 0); YK_CATCH(0)
+}
+yk_idx_t yk_var_set_elements_in_slice_from_var(yk_var_h v, yk_var_h src, const yk_idx_t* fs, const yk_idx_t* ft, const yk_idx_t* lt) {
+    YK_TRY
+    Var* x = V(v); Var* y = V(src);
+    if (x->dims.size() != y->dims.size()) YKH_THROW("set_elements_in_slice(): source and target vars have different numbers of dims");
+    std::vector<idx_t> f = vec(x, ft), l = vec(x, lt), sf = vec(y, fs), sl(sf);
+    size_t n = 1;
+    for (size_t p = 0; p < f.size(); p++) { if (l[p] < f[p]) return 0; sl[p] = sf[p] + (l[p] - f[p]); n *= (size_t)(l[p] - f[p] + 1); }
+    // staged through a host buffer in the target's precision (API convenience path, not a hot path)
+    const int eb = x->elem_bytes();
+    std::vector<char> buf(n * eb);
+    y->get_elements_in_slice(buf.data(), n, eb, sf, sl);
+    return x->set_elements_in_slice(buf.data(), n, eb, f, l);
+    YK_CATCH(0)
 }
 int yk_var_set_all_elements_same(yk_var_h v, double val) { YK_TRY V(v)->set_all_elements_same(val); return 0; YK_CATCH(1) }
 int yk_var_reduce_elements_in_slice(yk_var_h v, int mask, const yk_idx_t* f, const yk_idx_t* l, int strict, yk_reduction_t* out) {

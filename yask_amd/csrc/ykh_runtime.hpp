@@ -245,6 +245,7 @@ public:
     idx_t min_pad[MAX_DOMAIN_DIMS] = {0, 0, 0};
     idx_t extra_pad[MAX_DOMAIN_DIMS] = {0, 0, 0};
     bool overlap_comms = true;
+    bool step_wrap = false;        // set_step_wrap(): any step index is accepted and wrapped onto the slots
     idx_t min_exterior = 0;
     bool do_halo_exchange = true;
     bool auto_tune = false;        // tuned at prepare() when true

@@ -216,7 +216,7 @@ void Var::check_indices(const std::vector<idx_t>& idx, const char* fn, bool stri
                   std::to_string(dims.size()) + " for var '" + name + "'");
     if (clipped) *clipped = false;
     for (size_t p = 0; p < dims.size(); p++) {
-        if (dims[p].type == DIM_STEP && !check_step) continue;
+        if (dims[p].type == DIM_STEP && (!check_step || soln->step_wrap)) continue;
         idx_t lo = first_local_index((int)p), hi = last_local_index((int)p);
         if (idx[p] < lo || idx[p] > hi) {
             if (strict)
@@ -240,7 +240,7 @@ idx_t Var::for_boxes(const std::vector<idx_t>& first, const std::vector<idx_t>& 
     // clip (non-strict) or validate (strict)
     std::vector<idx_t> lo(first), hi(last);
     for (size_t p = 0; p < nd; p++) {
-        if (dims[p].type == DIM_STEP && update_step) continue;   // window follows the writes
+        if (dims[p].type == DIM_STEP && (update_step || soln->step_wrap)) continue;   // window follows the writes / wraps
         idx_t alo = first_local_index((int)p), ahi = last_local_index((int)p);
         if (strict) {
             if (lo[p] < alo || hi[p] > ahi)

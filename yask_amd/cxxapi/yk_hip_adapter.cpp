@@ -1,0 +1,392 @@
+// yk_hip_adapter.cpp -- the reference's C++ kernel API (yk_factory / yk_env / yk_solution / yk_var /
+// yk_stats, include/yask_kernel_api.hpp + include/aux/yk_{solution,var}_api.hpp) implemented as thin
+// forwarding subclasses over the C ABI of libyask_kernel.<stencil>.cdna4_hip.so
+// (include/yask_hip_c_api.h).  Built against the reference's own headers ($(REF)/include); with it,
+// programs written for YASK -- including the reference's API tests, src/kernel/tests/
+// yask_kernel_api_test.cpp and yask_kernel_api_exception_test.cpp -- compile and link unchanged
+// against the MI355X library.  This is the C++ binding INTEGRATION.md section 2a describes.
+//
+// Conventions: every C call is followed by chk(): a pending C-side error becomes a yask_exception with
+// the same text ("YASK error: ...").  Hooks (call_before/after_*) run on the caller thread around the
+// forwarded call, as in soln_apis.cpp:116-133.
+#include <cstring>
+#include <map>
+#include <sstream>
+
+#include "yask_kernel_api.hpp"
+#include "../../include/yask_hip_c_api.h"
+
+namespace yask {
+
+    namespace {
+        void chk() {
+            if (yk_last_error_code()) {
+                std::string m = yk_last_error();
+                yk_clear_error();
+                throw yask_exception(m);
+            }
+        }
+        void chk_rc(int rc) { if (rc) { chk(); throw yask_exception("YASK error: call into the cdna4_hip kernel library failed"); } }
+        yask_output_ptr g_debug;
+        bool g_trace = false;
+
+        class hip_env;
+        class hip_solution;
+
+        class hip_stats : public yk_stats {
+            yk_stats_t st;
+        public:
+            explicit hip_stats(const yk_stats_t& s) : st(s) {}
+            idx_t get_num_elements() override { return st.num_elements; }
+            idx_t get_num_steps_done() override { return st.num_steps_done; }
+            idx_t get_num_writes_done() override { return st.num_writes_done; }
+            idx_t get_est_fp_ops_done() override { return st.est_fp_ops_done; }
+            double get_elapsed_secs() override { return st.elapsed_secs; }
+        };
+
+        class hip_reduction : public yk_var::yk_reduction_result {
+            yk_reduction_t r;
+        public:
+            explicit hip_reduction(const yk_reduction_t& x) : r(x) {}
+            int get_reduction_mask() const override { return r.reduction_mask; }
+            idx_t get_num_elements_reduced() const override { return r.num_elements_reduced; }
+            double get_sum() const override { need(yk_var::yk_sum_reduction); return r.sum; }
+            double get_sum_squares() const override { need(yk_var::yk_sum_squares_reduction); return r.sum_squares; }
+            double get_product() const override { need(yk_var::yk_product_reduction); return r.product; }
+            double get_max() const override { need(yk_var::yk_max_reduction); return r.max; }
+            double get_min() const override { need(yk_var::yk_min_reduction); return r.min; }
+        private:
+            void need(int bit) const {
+                if (!(r.reduction_mask & bit)) THROW_YASK_EXCEPTION("reduction result requested that was not computed");
+            }
+        };
+
+        class hip_var : public yk_var {
+        public:
+            yk_var_h h;
+            hip_solution* soln;
+            std::string name;
+            hip_var(yk_var_h v, hip_solution* s) : h(v), soln(s), name(yk_var_get_name(v)) {}
+
+            const std::string& get_name() const override { return name; }
+            int get_num_dims() const override { return yk_var_get_num_dims(h); }
+            string_vec get_dim_names() const override {
+                string_vec v;
+                for (int i = 0; i < get_num_dims(); i++) v.push_back(yk_var_get_dim_name(h, i));
+                return v;
+            }
+            int get_num_domain_dims() const override;
+            bool is_dim_used(const std::string& dim) const override { return yk_var_is_dim_used(h, dim.c_str()) != 0; }
+            bool is_fixed_size() const override { return yk_var_is_fixed_size(h) != 0; }
+
+#define YKV_GET(name) \
+    idx_t name(const std::string& dim) const override { idx_t r = yk_var_##name(h, dim.c_str()); chk(); return r; }
+            YKV_GET(get_first_local_index) YKV_GET(get_last_local_index) YKV_GET(get_alloc_size)
+            YKV_GET(get_rank_domain_size) YKV_GET(get_first_rank_domain_index) YKV_GET(get_last_rank_domain_index)
+            YKV_GET(get_left_halo_size) YKV_GET(get_right_halo_size) YKV_GET(get_first_rank_halo_index)
+            YKV_GET(get_last_rank_halo_index) YKV_GET(get_left_pad_size) YKV_GET(get_right_pad_size)
+            YKV_GET(get_left_extra_pad_size) YKV_GET(get_right_extra_pad_size) YKV_GET(get_first_misc_index)
+            YKV_GET(get_last_misc_index)
+#undef YKV_GET
+            idx_t_vec all_dims(idx_t (hip_var::*fn)(const std::string&) const) const {
+                idx_t_vec v;
+                for (auto& d : get_dim_names()) v.push_back((this->*fn)(d));
+                return v;
+            }
+            idx_t_vec domain_dims(idx_t (hip_var::*fn)(const std::string&) const) const;
+            idx_t_vec get_first_local_index_vec() const override { return all_dims(&hip_var::get_first_local_index); }
+            idx_t_vec get_last_local_index_vec() const override { return all_dims(&hip_var::get_last_local_index); }
+            idx_t_vec get_alloc_size_vec() const override { return all_dims(&hip_var::get_alloc_size); }
+            idx_t_vec get_rank_domain_size_vec() const override { return domain_dims(&hip_var::get_rank_domain_size); }
+            idx_t_vec get_first_rank_domain_index_vec() const override { return domain_dims(&hip_var::get_first_rank_domain_index); }
+            idx_t_vec get_last_rank_domain_index_vec() const override { return domain_dims(&hip_var::get_last_rank_domain_index); }
+            idx_t_vec get_first_rank_halo_index_vec() const override { return domain_dims(&hip_var::get_first_rank_halo_index); }
+            idx_t_vec get_last_rank_halo_index_vec() const override { return domain_dims(&hip_var::get_last_rank_halo_index); }
+            idx_t get_first_valid_step_index() const override { idx_t r = yk_var_get_first_valid_step_index(h); chk(); return r; }
+            idx_t get_last_valid_step_index() const override { idx_t r = yk_var_get_last_valid_step_index(h); chk(); return r; }
+
+            void need_n(size_t n, const char* fn) const {
+                if ((int)n != get_num_dims())
+                    FORMAT_AND_THROW_YASK_EXCEPTION(fn << " called with " << n << " indices instead of " << get_num_dims() <<
+                                                    " for var '" << name << "'");
+            }
+            bool are_indices_local(const idx_t_vec& i) const override { need_n(i.size(), "are_indices_local()"); int r = yk_var_are_indices_local(h, i.data()); chk(); return r != 0; }
+            bool are_indices_local(const idx_t_init_list& i) const override { return are_indices_local(idx_t_vec(i)); }
+            double get_element(const idx_t_vec& i) const override { need_n(i.size(), "get_element()"); double r = yk_var_get_element(h, i.data()); chk(); return r; }
+            double get_element(const idx_t_init_list& i) const override { return get_element(idx_t_vec(i)); }
+            idx_t set_element(double val, const idx_t_vec& i, bool strict = true) override { need_n(i.size(), "set_element()"); idx_t r = yk_var_set_element(h, val, i.data(), strict); chk(); return r; }
+            idx_t set_element(double val, const idx_t_init_list& i, bool strict = true) override { return set_element(val, idx_t_vec(i), strict); }
+            idx_t add_to_element(double val, const idx_t_vec& i, bool strict = true) override { need_n(i.size(), "add_to_element()"); idx_t r = yk_var_add_to_element(h, val, i.data(), strict); chk(); return r; }
+            idx_t add_to_element(double val, const idx_t_init_list& i, bool strict = true) override { return add_to_element(val, idx_t_vec(i), strict); }
+
+            idx_t get_elements_in_slice(float* b, size_t n, const idx_t_vec& f, const idx_t_vec& l) const override {
+                need_n(f.size(), "get_elements_in_slice()"); need_n(l.size(), "get_elements_in_slice()");
+                idx_t r = yk_var_get_elements_in_slice_f32(h, b, n, f.data(), l.data()); chk(); return r; }
+            idx_t get_elements_in_slice(double* b, size_t n, const idx_t_vec& f, const idx_t_vec& l) const override {
+                need_n(f.size(), "get_elements_in_slice()"); need_n(l.size(), "get_elements_in_slice()");
+                idx_t r = yk_var_get_elements_in_slice_f64(h, b, n, f.data(), l.data()); chk(); return r; }
+            idx_t set_elements_in_slice(const float* b, size_t n, const idx_t_vec& f, const idx_t_vec& l) override {
+                need_n(f.size(), "set_elements_in_slice()"); need_n(l.size(), "set_elements_in_slice()");
+                idx_t r = yk_var_set_elements_in_slice_f32(h, b, n, f.data(), l.data()); chk(); return r; }
+            idx_t set_elements_in_slice(const double* b, size_t n, const idx_t_vec& f, const idx_t_vec& l) override {
+                need_n(f.size(), "set_elements_in_slice()"); need_n(l.size(), "set_elements_in_slice()");
+                idx_t r = yk_var_set_elements_in_slice_f64(h, b, n, f.data(), l.data()); chk(); return r; }
+            // (declared by the reference only under COPY_SLICE_IMPLEMENTED, yk_var_api.hpp:933-962)
+            idx_t set_elements_in_slice(const yk_var_ptr src, const idx_t_vec& fs, const idx_t_vec& ft, const idx_t_vec& lt)
+            #ifdef COPY_SLICE_IMPLEMENTED
+                override
+            #endif
+            {
+                auto* s = dynamic_cast<hip_var*>(src.get());
+                if (!s) THROW_YASK_EXCEPTION("set_elements_in_slice(): source var does not belong to a cdna4_hip solution");
+                need_n(ft.size(), "set_elements_in_slice()"); need_n(lt.size(), "set_elements_in_slice()");
+                idx_t r = yk_var_set_elements_in_slice_from_var(h, s->h, fs.data(), ft.data(), lt.data()); chk(); return r; }
+            // untyped buffers hold elements of the solution's precision (yk_var_api.hpp:1455-1480)
+            size_t slice_elems(const idx_t_vec& f, const idx_t_vec& l) const {
+                size_t n = 1;
+                for (size_t i = 0; i < f.size() && i < l.size(); i++) n *= (l[i] >= f[i]) ? size_t(l[i] - f[i] + 1) : 0;
+                return n;
+            }
+            idx_t get_elements_in_slice(void* b, const idx_t_vec& f, const idx_t_vec& l) const override;
+            idx_t set_elements_in_slice(const void* b, const idx_t_vec& f, const idx_t_vec& l) override;
+            void set_all_elements_same(double val) override { chk_rc(yk_var_set_all_elements_same(h, val)); }
+            idx_t set_elements_in_slice_same(double val, const idx_t_vec& f, const idx_t_vec& l, bool strict = true) override {
+                need_n(f.size(), "set_elements_in_slice_same()"); need_n(l.size(), "set_elements_in_slice_same()");
+                idx_t r = yk_var_set_elements_in_slice_same(h, val, f.data(), l.data(), strict); chk(); return r; }
+            yk_reduction_result_ptr reduce_elements_in_slice(int mask, const idx_t_vec& f, const idx_t_vec& l, bool strict = true) override {
+                need_n(f.size(), "reduce_elements_in_slice()"); need_n(l.size(), "reduce_elements_in_slice()");
+                yk_reduction_t r; chk_rc(yk_var_reduce_elements_in_slice(h, mask, f.data(), l.data(), strict, &r));
+                return std::make_shared<hip_reduction>(r); }
+            std::string format_indices(const idx_t_vec& idx) const override {
+                need_n(idx.size(), "format_indices()");
+                std::ostringstream os; auto dn = get_dim_names();
+                for (size_t i = 0; i < idx.size(); i++) os << (i ? ", " : "") << dn[i] << "=" << idx[i];
+                return os.str(); }
+            std::string format_indices(const idx_t_init_list& idx) const override { return format_indices(idx_t_vec(idx)); }
+            int get_halo_exchange_l1_norm() const override { return yk_var_get_halo_exchange_l1_norm(h); }
+            void set_halo_exchange_l1_norm(int n) override { chk_rc(yk_var_set_halo_exchange_l1_norm(h, n)); }
+            bool is_dynamic_step_alloc() const override { return yk_var_is_dynamic_step_alloc(h) != 0; }
+            bool set_numa_preferred(int) override { return false; }     // no NUMA policy on device memory
+            int get_numa_preferred() const override { return yask_numa_none; }
+#define YKV_SET(name) void name(const std::string& dim, idx_t n) override { chk_rc(yk_var_##name(h, dim.c_str(), n)); }
+            YKV_SET(set_left_min_pad_size) YKV_SET(set_right_min_pad_size) YKV_SET(set_min_pad_size)
+            YKV_SET(set_left_halo_size) YKV_SET(set_right_halo_size) YKV_SET(set_halo_size)
+            YKV_SET(set_alloc_size) YKV_SET(set_first_misc_index)
+#undef YKV_SET
+            bool is_storage_allocated() const override { return yk_var_is_storage_allocated(h) != 0; }
+            idx_t get_num_storage_bytes() const override { return yk_var_get_num_storage_bytes(h); }
+            idx_t get_num_storage_elements() const override { return yk_var_get_num_storage_elements(h); }
+            void alloc_storage() override { chk_rc(yk_var_alloc_storage(h)); }
+            void release_storage() override { chk_rc(yk_var_release_storage(h)); }
+            bool is_storage_layout_identical(const yk_var_ptr other) const override {
+                auto* o = dynamic_cast<hip_var*>(other.get());
+                return o && yk_var_is_storage_layout_identical(h, o->h) != 0; }
+            void fuse_vars(yk_var_ptr source) override {
+                auto* o = dynamic_cast<hip_var*>(source.get());
+                if (!o) THROW_YASK_EXCEPTION("fuse_vars(): source var does not belong to a cdna4_hip solution");
+                chk_rc(yk_var_fuse_vars(h, o->h)); }
+            void* get_raw_storage_buffer() override { void* p = yk_var_get_raw_storage_buffer(h); chk(); return p; }
+        };
+
+        class hip_env : public yk_env {
+        public:
+            yk_env_h h;
+            explicit hip_env(yk_env_h e) : h(e) {}
+            ~hip_env() override { if (h) yk_free_env(h); }
+            int get_num_ranks() const override { return yk_env_get_num_ranks(h); }
+            int get_rank_index() const override { return yk_env_get_rank_index(h); }
+            void global_barrier() const override { chk_rc(yk_env_global_barrier(h)); }
+            idx_t sum_over_ranks(idx_t v) const override { idx_t r = yk_env_sum_over_ranks(h, v); chk(); return r; }
+            void assert_equality_over_ranks(idx_t v, const std::string& descr) const override {
+                idx_t s = sum_over_ranks(v);
+                if (s != v * get_num_ranks())
+                    FORMAT_AND_THROW_YASK_EXCEPTION(descr << " values are not equal across all ranks");
+            }
+            void finalize() override {}
+            YASK_NORETURN void exit(int code) override { ::exit(code); }
+        };
+
+        class hip_solution : public yk_solution, public std::enable_shared_from_this<hip_solution> {
+        public:
+            yk_soln_h h;
+            std::shared_ptr<hip_env> env;
+            std::string name, descr;
+            std::map<yk_var_h, yk_var_ptr> wrapped;
+            std::vector<hook_fn_t> before_prep, after_prep;
+            std::vector<hook_fn_2idx_t> before_run, after_run;
+            hip_solution(yk_soln_h s, std::shared_ptr<hip_env> e) : h(s), env(e), name(yk_solution_get_name(s)), descr(yk_solution_get_description(s)) {}
+            ~hip_solution() override { wrapped.clear(); if (h) yk_free_solution(h); }
+
+            const std::string& get_name() const override { return name; }
+            const std::string& get_description() const override { return descr; }
+            std::string get_target() const override { return yk_solution_get_target(h); }
+            bool is_offloaded() const override { return yk_solution_is_offloaded(h) != 0; }
+            int get_element_bytes() const override { return yk_solution_get_element_bytes(h); }
+            std::string get_step_dim_name() const override { return yk_solution_get_step_dim_name(h); }
+            int get_num_domain_dims() const override { return yk_solution_get_num_domain_dims(h); }
+            string_vec get_domain_dim_names() const override {
+                string_vec v; for (int i = 0; i < get_num_domain_dims(); i++) v.push_back(yk_solution_get_domain_dim_name(h, i)); return v; }
+            string_vec get_misc_dim_names() const override {
+                string_vec v; for (int i = 0; i < yk_solution_get_num_misc_dims(h); i++) v.push_back(yk_solution_get_misc_dim_name(h, i)); return v; }
+
+#define YKS_DIM(prop) \
+    void set_##prop(const std::string& dim, idx_t n) override { chk_rc(yk_solution_set_##prop(h, dim.c_str(), n)); } \
+    idx_t get_##prop(const std::string& dim) const override { idx_t r = yk_solution_get_##prop(h, dim.c_str()); chk(); return r; } \
+    void set_##prop##_vec(const idx_t_vec& v) override { set_vec(v, #prop, [&](const std::string& d, idx_t n) { set_##prop(d, n); }); } \
+    void set_##prop##_vec(const idx_t_init_list& v) override { set_##prop##_vec(idx_t_vec(v)); } \
+    idx_t_vec get_##prop##_vec() const override { idx_t_vec r; for (auto& d : get_domain_dim_names()) r.push_back(get_##prop(d)); return r; }
+            template <class F> void set_vec(const idx_t_vec& v, const char* what, F f) {
+                auto dn = get_domain_dim_names();
+                if (v.size() != dn.size())
+                    FORMAT_AND_THROW_YASK_EXCEPTION("set_" << what << "_vec() called with " << v.size() << " value(s) instead of " << dn.size());
+                for (size_t i = 0; i < dn.size(); i++) f(dn[i], v[i]);
+            }
+            YKS_DIM(rank_domain_size) YKS_DIM(overall_domain_size) YKS_DIM(num_ranks) YKS_DIM(rank_index)
+#undef YKS_DIM
+            // block sizes also accept the step dim (yk_solution_api.hpp:316-373)
+            void set_block_size(const std::string& dim, idx_t n) override { chk_rc(yk_solution_set_block_size(h, dim.c_str(), n)); }
+            idx_t get_block_size(const std::string& dim) const override { idx_t r = yk_solution_get_block_size(h, dim.c_str()); chk(); return r; }
+            void set_block_size_vec(const idx_t_vec& v) override { set_vec(v, "block_size", [&](const std::string& d, idx_t n) { set_block_size(d, n); }); }
+            void set_block_size_vec(const idx_t_init_list& v) override { set_block_size_vec(idx_t_vec(v)); }
+            idx_t_vec get_block_size_vec() const override { idx_t_vec r; for (auto& d : get_domain_dim_names()) r.push_back(get_block_size(d)); return r; }
+            int get_num_outer_threads() const override { return 1; }
+            int get_num_inner_threads() const override { return 1; }
+
+            std::string apply_command_line_options(const std::string& args) override {
+                std::vector<char> rem(args.size() + 16);
+                chk_rc(yk_solution_apply_command_line_options(h, args.c_str(), rem.data(), rem.size()));
+                return std::string(rem.data());
+            }
+            std::string apply_command_line_options(int argc, char* argv[]) override {
+                string_vec v; for (int i = 1; i < argc; i++) v.push_back(argv[i]); return apply_command_line_options(v); }
+            std::string apply_command_line_options(const string_vec& args) override {
+                std::string s; for (auto& a : args) s += (s.empty() ? "" : " ") + a; return apply_command_line_options(s); }
+            std::string get_command_line_help() override { return yk_solution_get_command_line_help(h); }
+            std::string get_command_line_values() override { return yk_solution_get_command_line_values(h); }
+
+            yk_var_ptr wrap(yk_var_h v) {
+                if (!v) { chk(); THROW_YASK_EXCEPTION("var not found"); }
+                auto it = wrapped.find(v);
+                if (it != wrapped.end()) return it->second;
+                yk_var_ptr p = std::make_shared<hip_var>(v, this);
+                wrapped[v] = p;
+                return p;
+            }
+            int get_num_vars() const override { return yk_solution_get_num_vars(h); }
+            yk_var_ptr get_var(const std::string& n) override { yk_var_h v = yk_solution_get_var(h, n.c_str()); chk(); return wrap(v); }
+            std::vector<yk_var_ptr> get_vars() override {
+                std::vector<yk_var_ptr> r; for (int i = 0; i < get_num_vars(); i++) r.push_back(wrap(yk_solution_get_var_by_index(h, i))); return r; }
+            void prepare_solution() override {
+                for (auto& f : before_prep) f(*this);
+                chk_rc(yk_solution_prepare(h));
+                for (auto& f : after_prep) f(*this);
+            }
+            idx_t get_first_rank_domain_index(const std::string& d) const override { idx_t r = yk_solution_get_first_rank_domain_index(h, d.c_str()); chk(); return r; }
+            idx_t get_last_rank_domain_index(const std::string& d) const override { idx_t r = yk_solution_get_last_rank_domain_index(h, d.c_str()); chk(); return r; }
+            idx_t_vec get_first_rank_domain_index_vec() const override { idx_t_vec r; for (auto& d : get_domain_dim_names()) r.push_back(get_first_rank_domain_index(d)); return r; }
+            idx_t_vec get_last_rank_domain_index_vec() const override { idx_t_vec r; for (auto& d : get_domain_dim_names()) r.push_back(get_last_rank_domain_index(d)); return r; }
+            void run_solution(idx_t first, idx_t last) override {
+                for (auto& f : before_run) f(*this, first, last);
+                chk_rc(yk_solution_run(h, first, last));
+                for (auto& f : after_run) f(*this, first, last);
+            }
+            void run_solution(idx_t step) override { run_solution(step, step); }
+            void copy_vars_to_device() const override { chk_rc(yk_solution_copy_vars_to_device(h)); }
+            void copy_vars_from_device() const override { chk_rc(yk_solution_copy_vars_from_device(h)); }
+            void exchange_halos() override { chk_rc(yk_solution_exchange_halos(h)); }
+            void end_solution() override { chk_rc(yk_solution_end(h)); }
+            yk_stats_ptr get_stats() override { yk_stats_t st; chk_rc(yk_solution_get_stats(h, &st)); return std::make_shared<hip_stats>(st); }
+            void clear_stats() override { chk_rc(yk_solution_clear_stats(h)); }
+            void reset_auto_tuner(bool enable, bool verbose = false) override { chk_rc(yk_solution_reset_auto_tuner(h, enable, verbose)); }
+            bool is_auto_tuner_enabled() const override { return yk_solution_is_auto_tuner_enabled(h) != 0; }
+            void run_auto_tuner_now(bool verbose = true) override { chk_rc(yk_solution_run_auto_tuner_now(h, verbose)); }
+            void set_min_pad_size(const std::string& d, idx_t n) override { chk_rc(yk_solution_set_min_pad_size(h, d.c_str(), n)); }
+            idx_t get_min_pad_size(const std::string& d) const override { idx_t r = yk_solution_get_min_pad_size(h, d.c_str()); chk(); return r; }
+            yk_var_ptr new_var(const std::string& n, const string_vec& dims) override {
+                std::vector<const char*> d; for (auto& s : dims) d.push_back(s.c_str());
+                yk_var_h v = yk_solution_new_var(h, n.c_str(), (int)d.size(), d.data()); chk(); return wrap(v); }
+            yk_var_ptr new_var(const std::string& n, const std::initializer_list<std::string>& dims) override { return new_var(n, string_vec(dims)); }
+            yk_var_ptr new_fixed_size_var(const std::string& n, const string_vec& dims, const idx_t_vec& sizes) override {
+                if (dims.size() != sizes.size()) THROW_YASK_EXCEPTION("new_fixed_size_var(): number of dims and sizes differ");
+                std::vector<const char*> d; for (auto& s : dims) d.push_back(s.c_str());
+                yk_var_h v = yk_solution_new_fixed_size_var(h, n.c_str(), (int)d.size(), d.data(), sizes.data()); chk(); return wrap(v); }
+            yk_var_ptr new_fixed_size_var(const std::string& n, const std::initializer_list<std::string>& dims, const idx_t_init_list& sizes) override {
+                return new_fixed_size_var(n, string_vec(dims), idx_t_vec(sizes)); }
+            bool set_default_numa_preferred(int) override { return false; }
+            int get_default_numa_preferred() const override { return yask_numa_none; }
+            void call_before_prepare_solution(hook_fn_t f) override { before_prep.push_back(f); }
+            void call_after_prepare_solution(hook_fn_t f) override { after_prep.push_back(f); }
+            void call_before_run_solution(hook_fn_2idx_t f) override { before_run.push_back(f); }
+            void call_after_run_solution(hook_fn_2idx_t f) override { after_run.push_back(f); }
+            void fuse_vars(yk_solution_ptr source) override {
+                // fuse every var of this solution with the like-named var of `source` (yk_solution_api.hpp:1200-1207)
+                for (auto& v : get_vars()) {
+                    yk_var_ptr sv;
+                    try { sv = source->get_var(v->get_name()); } catch (yask_exception&) { continue; }
+                    v->fuse_vars(sv);
+                }
+            }
+            void set_step_wrap(bool w) override { chk_rc(yk_solution_set_step_wrap(h, w)); }
+            bool get_step_wrap() const override { return yk_solution_get_step_wrap(h) != 0; }
+            void set_debug_output(yask_output_ptr d) override { yk_env::set_debug_output(d); }
+        };
+
+        int hip_var::get_num_domain_dims() const {
+            int n = 0;
+            auto dd = soln->get_domain_dim_names();
+            for (auto& d : get_dim_names()) for (auto& x : dd) if (d == x) n++;
+            return n;
+        }
+        idx_t_vec hip_var::domain_dims(idx_t (hip_var::*fn)(const std::string&) const) const {
+            idx_t_vec v;
+            auto dd = soln->get_domain_dim_names();
+            for (auto& d : get_dim_names()) for (auto& x : dd) if (d == x) v.push_back((this->*fn)(d));
+            return v;
+        }
+        idx_t hip_var::get_elements_in_slice(void* b, const idx_t_vec& f, const idx_t_vec& l) const {
+            return soln->get_element_bytes() == 4 ? get_elements_in_slice((float*)b, slice_elems(f, l), f, l)
+                                                  : get_elements_in_slice((double*)b, slice_elems(f, l), f, l);
+        }
+        idx_t hip_var::set_elements_in_slice(const void* b, const idx_t_vec& f, const idx_t_vec& l) {
+            return soln->get_element_bytes() == 4 ? set_elements_in_slice((const float*)b, slice_elems(f, l), f, l)
+                                                  : set_elements_in_slice((const double*)b, slice_elems(f, l), f, l);
+        }
+    } // anon namespace.
+
+    // ---- out-of-line members the reference's kernel library defines (factory.cpp, settings.cpp, setup.cpp)
+    yk_factory::yk_factory() {}
+    std::string yk_factory::get_version_string() { return yk_get_version_string(); }
+    yk_env_ptr yk_factory::new_env() const {
+        yk_env_h e = yk_new_env();
+        chk();
+        if (!e) THROW_YASK_EXCEPTION("cannot create a cdna4_hip env");
+        auto p = std::make_shared<hip_env>(e);
+        if (g_trace) yk_env_set_trace_enabled(e, 1);
+        return p;
+    }
+    yk_env_ptr yk_factory::new_env(MPI_Comm) const { return new_env(); }   // one process per GPU: ranks come from yk_env_init_rccl()
+    yk_solution_ptr yk_factory::new_solution(yk_env_ptr env) const {
+        auto e = std::dynamic_pointer_cast<hip_env>(env);
+        if (!e) THROW_YASK_EXCEPTION("new_solution() called without a cdna4_hip env");
+        yk_soln_h s = yk_new_solution(e->h);
+        chk();
+        return std::make_shared<hip_solution>(s, e);
+    }
+    yk_solution_ptr yk_factory::new_solution(yk_env_ptr env, const yk_solution_ptr source) const {
+        auto e = std::dynamic_pointer_cast<hip_env>(env);
+        auto src = std::dynamic_pointer_cast<hip_solution>(source);
+        if (!e || !src) THROW_YASK_EXCEPTION("new_solution() called without a cdna4_hip env/source");
+        yk_soln_h s = yk_new_solution_from(e->h, src->h);
+        chk();
+        return std::make_shared<hip_solution>(s, e);
+    }
+    yask_output_ptr yk_env::get_debug_output() {
+        if (!g_debug) { yask_output_factory yof; g_debug = yof.new_stdout_output(); }
+        return g_debug;
+    }
+    void yk_env::set_debug_output(yask_output_ptr debug) { g_debug = debug; }
+    void yk_env::disable_debug_output() { yask_output_factory yof; g_debug = yof.new_null_output(); }
+    void yk_env::set_trace_enabled(bool enable) { g_trace = enable; }
+    bool yk_env::is_trace_enabled() { return g_trace; }
+
+} // namespace yask.
