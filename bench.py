@@ -25,8 +25,21 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-BYTES_PER_POINT = 16.0       # read p(t) 4 + p(t-1) 4 + v 4, write p(t+1) 4
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+# workload -> (stencil library, description, default points per GPU per dim, dtype, algorithmic bytes per
+# point-step, init: var -> (offset, scale, hash id))
+WORKLOADS = {
+    # BASELINE.json configs[1] -- the headline: read p(t) 4 + p(t-1) 4 + v 4, write p(t+1) 4
+    "iso3dfd": ("iso3dfd", "iso3dfd r=8 fp32", 1024, "f32", 16.0, {"p": (0.0, 1.0, 0), "v": (150.0, 50.0, 1)}),
+    # configs[2]: read 8 + write 8
+    "3axis": ("3axis", "3axis r=4 fp64", 512, "f64", 16.0, {"A": (0.0, 1.0, 0)}),
+    # configs[4]: stage 1 (10 reads + 3 writes) + stage 2 (12 reads + 6 writes), 4 B each
+    "ssg": ("ssg", "ssg staggered-grid elastic fp32 (2 stages)", 512, "f32", 124.0,
+            {**{f: (0.0, 1.0e-3, i + 1) for i, f in enumerate(["v_bl_w", "v_tl_v", "v_tr_u", "s_bl_yz", "s_br_xz", "s_tl_xx",
+                                                              "s_tl_yy", "s_tl_zz", "s_tr_xy"])},
+             "rho": (1.5, 0.5, 0), "mu": (1.5, 0.5, 10), "lambda": (1.5, 0.5, 11), "lambdamu2": (1.5, 0.5, 12)}),
+}
 
 
 def cpu_baseline(n=512, steps=10):
@@ -64,7 +77,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--size", type=int, default=1024, help="points per GPU in each dim")
+    ap.add_argument("--workload", default="iso3dfd", choices=sorted(WORKLOADS), help="default: the headline (BASELINE.json configs[1])")
+    ap.add_argument("--size", type=int, default=0, help="points per GPU in each dim (default: the workload's configured size)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"])
     ap.add_argument("--opts", default="", help="extra yask options, e.g. '-hip_variant NAME'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -76,10 +90,11 @@ def main():
     rank, local_rank, world = ydist.init_process_group()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    fac = yk_factory("iso3dfd")
+    stencil, descr, dflt_n, dtype, BYTES_PER_POINT, init = WORKLOADS[args.workload]
+    fac = yk_factory(stencil)
     env, transport = ydist.new_env(fac, args.transport)
     soln = fac.new_solution(env)
-    n = args.size
+    n = args.size or dflt_n
     # x-slab decomposition: x-faces are whole contiguous planes and each GPU has only 2 neighbours
     soln.set_num_ranks_vec([world, 1, 1])
     soln.set_rank_domain_size_vec([n, n, n])
@@ -87,8 +102,8 @@ def main():
         rem = soln.apply_command_line_options(args.opts)
         assert rem == "", rem
     soln.prepare_solution()
-    soln.get_var("p").set_elements_hash(0.0, 1.0, hash_id=0)
-    soln.get_var("v").set_elements_hash(150.0, 50.0, hash_id=1)
+    for name, (off, sc, hid) in init.items():
+        soln.get_var(name).set_elements_hash(off, sc, hash_id=hid)
 
     def barrier():
         torch.cuda.synchronize()
@@ -115,12 +130,14 @@ def main():
     total_pts = pts_per_gpu * world
     value = total_pts * args.steps / elapsed * 1e-9
 
-    # dominant kernel: average launch duration by HIP events on the compute stream, same launches
-    kern_ms = soln.time_part(part=0, variant=-1, t=t, reps=max(10, min(args.steps, 50)))
+    # dominant kernel(s): average launch duration by HIP events on the compute stream, same launches
+    # (multi-stage solutions: the sum over their parts = one step's worth of launches)
+    nparts = soln.get_num_parts()
+    kern_ms = sum(soln.time_part(part=p, variant=-1, t=t, reps=max(10, min(args.steps, 50))) for p in range(nparts))
     achieved = BYTES_PER_POINT * pts_per_gpu / (kern_ms * 1e-3) * 1e-9
     traffic = None
     tf = ROOT / "profiles" / "hbm_traffic.json"
-    if tf.exists():
+    if tf.exists() and args.workload == "iso3dfd" and n == 1024:
         try:
             traffic = json.load(open(tf)).get("iso3dfd_1024_bytes_per_launch")
         except Exception:  # noqa: BLE001
@@ -128,19 +145,19 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Gpoints/s (grid updates/s), iso3dfd 16th-order fp32",
+            "metric": "Gpoints/s (grid updates/s), " + ("iso3dfd 16th-order fp32" if args.workload == "iso3dfd" else descr),
             "value": round(value, 3), "unit": "Gpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (logical-index hash init, random-like)",
-            "config": {"workload": f"iso3dfd r=8 fp32, {n}^3 points per GPU, global {n * world}x{n}x{n}",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic (logical-index hash init, random-like)",
+            "config": {"workload": f"{descr}, {n}^3 points per GPU, global {n * world}x{n}x{n}",
                        "decomposition": f"x-slabs {world}x1x1", "halo_transport": transport,
-                       "kernel": soln.get_kernel_variant(0), "overlap_comms": True},
+                       "kernel": "+".join(soln.get_kernel_variant(p) for p in range(nparts)), "overlap_comms": True},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": BYTES_PER_POINT * pts_per_gpu},
             "gpoints_per_s_per_gpu": round(value / world, 3),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "iso3dfd":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

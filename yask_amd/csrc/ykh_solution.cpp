@@ -454,11 +454,23 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
         }
         idx_t xc = xchunk;
         if (xc <= 0) {
-            // default: march the whole box unless that leaves the chip short of workgroups
-            idx_t tiles = (idx_t)a.ntz * a.nty;
-            idx_t want = env->num_cus;   // one block per CU at least; whole-x marches otherwise (fewest halo planes)
-            idx_t nchunks = std::max<idx_t>(1, std::min<idx_t>(ceil_div(want, tiles), ceil_div(nx, 64)));
-            xc = ceil_div(nx, nchunks);
+            // default x-chunking: the (y,z) tiles times the number of x-chunks should fill the CUs in whole
+            // rounds (a 576-tile plane on 256 CUs would otherwise run 3 rounds for 2.25 rounds of work),
+            // while every chunk re-loads the x-halo planes of its neighbours (cost ~ xhalo / chunk length).
+            const idx_t tiles = (idx_t)a.ntz * a.nty;
+            const idx_t cus = std::max(1, env->num_cus);
+            idx_t xhalo = shared_pad_l_[0] + shared_pad_r_[0];
+            double best_eff = -1;
+            idx_t best_n = 1;
+            for (idx_t n = 1; n <= 32; n++) {
+                idx_t len = ceil_div(nx, n);
+                if (n > 1 && len < 32) break;
+                idx_t blocks = tiles * ceil_div(nx, len);
+                double fill = (double)blocks / (double)(ceil_div(blocks, cus) * cus);
+                double eff = fill * (double)len / (double)(len + xhalo);
+                if (eff > best_eff * 1.02) { best_eff = eff; best_n = n; }   // prefer fewer chunks on near-ties
+            }
+            xc = ceil_div(nx, best_n);
         }
         xc = std::max<idx_t>(1, std::min(xc, nx));
         a.xchunk = (int)xc;
