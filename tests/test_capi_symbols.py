@@ -11,7 +11,7 @@ def test_header_and_prototype_table_agree():
         set(_capi.header_symbols()) ^ set(_capi.PROTOTYPES))
 
 
-@pytest.mark.parametrize("stencil", ["iso3dfd", "3axis", "ssg", "test_3d"])
+@pytest.mark.parametrize("stencil", ["iso3dfd", "3axis", "ssg", "test_3d", "test_boundary_3d", "test_scratch_3d", "test_misc_2d"])
 def test_library_exports_all_symbols(stencil):
     p = _capi.lib_path(stencil)
     assert p.exists(), f"{p} missing: run __graft_entry__.build()"

@@ -1,0 +1,79 @@
+"""The reference's own test stencils (src/stencils/TestStencils.cpp -- the matrix its `stencil-tests`
+target validates, src/kernel/Makefile:1101-1182) rendered by the `cdna4_hip` compiler target as they are
+and run on the GPU, against golden outputs of the UNMODIFIED reference CPU kernel (tests/golden/
+make_golden.py).  Covers what the three hot-path stencils do not: sub-domain (IF_DOMAIN) conditions,
+scratch vars (chained, with boundaries), misc dims with constant indices, vars over a subset of the
+domain dims, multiple stages, math functions, 1-D and 2-D solutions.
+Tolerance (fp32): max|gpu-ref| / max|ref| <= 2e-5 per array (values grow by ~10x per step here)."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).resolve().parent / "golden"
+INDEX = json.load(open(G / "index.json"))
+CASES = [n for n in INDEX if INDEX[n].get("generic")]
+
+
+def _slice(soln, var, t):
+    dn = var.get_dim_names()
+    dom = soln.get_domain_dim_names()
+    sdim = soln.get_step_dim_name()
+    first, last, squeeze = [], [], None
+    for i, d in enumerate(dn):
+        if d == sdim:
+            first.append(t); last.append(t); squeeze = i
+        elif d in dom:
+            first.append(var.get_first_rank_domain_index(d)); last.append(var.get_last_rank_domain_index(d))
+        else:
+            first.append(var.get_first_misc_index(d)); last.append(var.get_last_misc_index(d))
+    if not dn:
+        return np.asarray(var.get_element([]))
+    a = var.get_elements_in_slice(first, last)
+    return a[0] if squeeze == 0 else a
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_reference_test_stencil_matches_reference(gpu, name):
+    from yask_amd import yk_factory
+    meta = INDEX[name]
+    z = np.load(G / f"{name}.npz")
+    fac = yk_factory(meta["stencil"])
+    soln = fac.new_solution(fac.new_env())
+    soln.set_overall_domain_size_vec(meta["size"])
+    soln.prepare_solution()
+    off, sc = meta["init"]
+    for i, v in enumerate(soln.get_vars()):
+        v.set_elements_hash(off, sc, hash_id=i)
+    soln.run_solution(0, meta["steps"] - 1)
+    checked = 0
+    for key in meta["arrays"]:
+        vname, t = key.split("@")
+        var = soln.get_var(vname)
+        got = np.asarray(_slice(soln, var, int(t)), dtype=np.float64)
+        ref = z[key].astype(np.float64)
+        assert got.shape == ref.shape, (key, got.shape, ref.shape)
+        assert np.isfinite(ref).all()
+        err = np.abs(got - ref).max() / max(1e-30, np.abs(ref).max())
+        assert err <= 2e-5, (key, err)
+        checked += 1
+    assert checked == len(meta["arrays"])
+    # every variant of every part gives the same answer (bit-exact is not required between shapes)
+    for part in range(soln.get_num_parts()):
+        for vn in soln.get_kernel_variant_names(part):
+            if vn.startswith("abl"):
+                continue
+            s2 = fac.new_solution(fac.new_env())
+            s2.set_overall_domain_size_vec(meta["size"])
+            s2.apply_command_line_options(f"-hip_variant {vn}")
+            s2.prepare_solution()
+            for i, v in enumerate(s2.get_vars()):
+                v.set_elements_hash(off, sc, hash_id=i)
+            s2.run_solution(0, meta["steps"] - 1)
+            for key in meta["arrays"]:
+                vname, t = key.split("@")
+                got = np.asarray(_slice(s2, s2.get_var(vname), int(t)), dtype=np.float64)
+                ref = z[key].astype(np.float64)
+                assert np.abs(got - ref).max() / max(1e-30, np.abs(ref).max()) <= 2e-5, (vn, key)

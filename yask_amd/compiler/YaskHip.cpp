@@ -157,7 +157,7 @@ namespace yask {
             string visit(FuncExpr* fe) override {
                 string s = "ykh::fn_" + fe->get_op_str() + "(";
                 bool first = true;
-                for (auto& op : fe->get_ops()) { s += (first ? "" : ", ") + op->accept(this); first = false; }
+                for (auto& op : fe->get_ops()) { s += string(first ? "" : ", ") + "V(" + op->accept(this) + ")"; first = false; }
                 return temp(fe->make_str(), s + ")");
             }
             string visit(UnaryNum2BoolExpr*) override { return fail("boolean expression in a value"); }
@@ -176,6 +176,53 @@ namespace yask {
                 body << "        a.template wr<" << gi << ">(" << rhs << ");\n";
                 return "";
             }
+        };
+
+
+        // Renders sub-domain (IF_DOMAIN) and step (IF_STEP) conditions as integer/boolean C++ expressions over
+        // scalar indices: a.sidx<D>() = global index of the point, a.first_idx<D>()/last_idx<D>() = first/last
+        // index of the overall domain (yc_node_factory::new_first/last_domain_index), `t` = the step index.
+        class CondEmitter : public ExprVisitor {
+        public:
+            const DimCtx& dc;
+            bool step_only;          // IF_STEP: only the step index may appear
+            bool failed = false;
+            string fail_why;
+            CondEmitter(const DimCtx& d, bool so) : dc(d), step_only(so) {}
+            string fail(const string& why) { failed = true; if (fail_why.empty()) fail_why = why; return "0"; }
+            string visit(ConstExpr* ce) override {
+                double v = ce->get_num_val();
+                if (double((long long)v) == v) return "(long long)" + to_string((long long)v);
+                return "(" + fmt_real(v) + ")";
+            }
+            string visit(CodeExpr*) override { return fail("hand-written code expression in a condition"); }
+            string visit(IndexExpr* ie) override {
+                auto type = ie->get_type();
+                if (type == STEP_INDEX) return step_only ? "t" : "a.sstep()";
+                if (step_only) return fail("non-step index in a step condition");
+                string d = to_string(dc.domain_idx(ie->_get_name()));
+                if (type == DOMAIN_INDEX) return "a.template sidx<" + d + ">()";
+                if (type == FIRST_INDEX) return "a.template first_idx<" + d + ">()";
+                if (type == LAST_INDEX) return "a.template last_idx<" + d + ">()";
+                return fail("misc index in a condition");
+            }
+            string visit(VarPoint*) override { return fail("var value in a condition"); }
+            string visit(UnaryNumExpr* ue) override { return "(" + ue->get_op_str() + ue->_get_rhs()->accept(this) + ")"; }
+            string visit(UnaryNum2BoolExpr* ue) override { return "(" + ue->get_op_str() + ue->_get_rhs()->accept(this) + ")"; }
+            string visit(UnaryBoolExpr* ue) override { return "(" + ue->get_op_str() + ue->_get_rhs()->accept(this) + ")"; }
+            string visit(BinaryNumExpr* be) override {
+                return "(" + be->_get_lhs()->accept(this) + " " + be->get_op_str() + " " + be->_get_rhs()->accept(this) + ")"; }
+            string visit(BinaryNum2BoolExpr* be) override {
+                return "(" + be->_get_lhs()->accept(this) + " " + be->get_op_str() + " " + be->_get_rhs()->accept(this) + ")"; }
+            string visit(BinaryBoolExpr* be) override {
+                return "(" + be->_get_lhs()->accept(this) + " " + be->get_op_str() + " " + be->_get_rhs()->accept(this) + ")"; }
+            string visit(CommutativeExpr* ce) override {
+                string r;
+                for (auto& op : ce->get_ops()) r += (r.empty() ? "" : " " + ce->get_op_str() + " ") + op->accept(this);
+                return "(" + r + ")";
+            }
+            string visit(FuncExpr*) override { return fail("function call in a condition"); }
+            string visit(EqualsExpr*) override { return fail("equation in a condition"); }
         };
 
         // Linear-form analysis (bottom-up, no code generation).
@@ -289,7 +336,7 @@ namespace yask {
         os << "// Automatically generated by the YASK stencil compiler, format-target 'cdna4_hip'\n"
               "// (yask_amd/compiler/YaskHip.cpp).  Stencil solution '" << sname << "', " << ebytes << "-byte reals.\n"
               "// DO NOT EDIT: regenerate with `make -C yask_amd/compiler gen`.\n"
-              "#pragma once\n#include <hip/hip_runtime.h>\n#include \"ykh_meta.hpp\"\n\n"
+              "#pragma once\n#include <hip/hip_runtime.h>\n#include \"ykh_meta.hpp\"\n#include \"ykh_fn.hpp\"\n\n"
               "namespace ykh_gen_" << c_ident(sname) << " {\nusing namespace ykh;\ntypedef " << real_t << " real_t;\n\n";
 
         // ---- dims: step, domain (outer -> inner), misc.
@@ -370,8 +417,22 @@ namespace yask {
                                          sname + "': " + em.fail_why);
 
                 // sub-domain / step conditions: rendered as predicates over the indices.
-                string cond_code, step_cond_code;
+                string cond_code = "true", step_cond_code = "true";
                 bool has_cond = part->cond.get() != 0, has_step_cond = part->step_cond.get() != 0;
+                if (has_cond) {
+                    CondEmitter ce(dc, false);
+                    cond_code = part->cond->accept(&ce);
+                    if (ce.failed)
+                        THROW_YASK_EXCEPTION("the 'cdna4_hip' target cannot render the sub-domain condition of part '" + pname +
+                                             "' of solution '" + sname + "': " + ce.fail_why);
+                }
+                if (has_step_cond) {
+                    CondEmitter ce(dc, true);
+                    step_cond_code = part->step_cond->accept(&ce);
+                    if (ce.failed)
+                        THROW_YASK_EXCEPTION("the 'cdna4_hip' target cannot render the step condition of part '" + pname +
+                                             "' of solution '" + sname + "': " + ce.fail_why);
+                }
 
                 // linear star form?
                 bool has_lin = false;
@@ -455,20 +516,23 @@ namespace yask {
                           "        typedef typename A::V V;\n" << lin_body << "    }\n";
                 } else
                     os << "    static constexpr bool has_lin = false;\n";
+                os << "\n    // IF_DOMAIN / IF_STEP conditions of this part" << (has_cond || has_step_cond ? "" : " (none)") << ".\n"
+                      "    static constexpr bool has_domain_cond = " << (has_cond ? "true" : "false") << ";\n"
+                      "    template <class A>\n    __device__ __forceinline__ static bool cond(const A& a) { return " << cond_code << "; }\n"
+                      "    static constexpr bool has_step_cond = " << (has_step_cond ? "true" : "false") << ";\n"
+                      "    static bool step_cond(long long t) { return " << step_cond_code << "; }\n";
                 os << "};\n\n";
 
                 ostringstream pm;
                 pm << "    {\"" << pname << "\", " << pname << "::n_groups, " << pname << "::groups, " << pname << "::n_reads, "
                    << pname << "::reads, " << pname << "::n_writes, " << pname << "::writes,\n     " << stats.get_num_ops() << ", "
                    << stats.get_num_reads() << ", " << stats.get_num_writes() << ", " << stage_no << ", "
-                   << (has_cond ? "true" : "false") << ", " << (has_step_cond ? "true" : "false") << "},\n";
+                   << (has_cond ? "true" : "false") << ", " << (has_step_cond ? "true" : "false") << ", "
+                   << (part->is_scratch() ? "true" : "false") << ", &" << pname << "::step_cond},\n";
                 part_idx[pname] = (int)part_names.size();
                 members.push_back((int)part_names.size());
                 part_names.push_back(pname);
                 part_meta.push_back(pm.str());
-                if (has_cond || has_step_cond)
-                    THROW_YASK_EXCEPTION("the 'cdna4_hip' target does not yet render sub-domain or step conditions (part '" +
-                                         pname + "' of solution '" + sname + "')");
             }
             if (!st->is_scratch() || !members.empty())
                 stages.push_back({st->_get_name(), members});

@@ -20,7 +20,7 @@ const SolnImpl& ykh_solution_impl() {
             PartImpl p;                                                                             \
             p.meta = &parts[pi++];                                                                  \
             p.variants.push_back(naive_variant<PART>());                                            \
-            if (ndd == 3) {                                                                         \
+            if (ndd == 3 && !PART::has_domain_cond) {                                               \
                 p.variants.push_back(vecpt_variant<PART, 16 / (int)sizeof(real_t), 64, 4, 1>());    \
                 p.default_variant = 1;                                                              \
             }                                                                                       \

@@ -30,6 +30,7 @@
 #include <type_traits>
 #include <utility>
 #include "ykh_meta.hpp"
+#include "ykh_fn.hpp"
 
 namespace ykh {
 
@@ -69,6 +70,7 @@ struct PartArgs {
     int ax0, ax1, ay0, ay1, az0, az1;   // allocated extent [lo, hi) of the shared layout (load clamps)
     int ntz, nty, nxc, xchunk;    // star25d tiling: tiles in z, y; chunks and chunk length in x
     int ofs_x, ofs_y, ofs_z;      // global index of local 0 (rank offset), for index expressions
+    int glast_x, glast_y, glast_z;   // last index of the overall domain (first is 0), for IF_DOMAIN conditions
     idx_t t;                      // evaluation step
 };
 
@@ -146,6 +148,14 @@ struct NaiveAcc {
     template <int D>
     __device__ __forceinline__ V idx() const { return V(D == 0 ? x + a.ofs_x : (D == 1 ? y + a.ofs_y : z + a.ofs_z)); }
     __device__ __forceinline__ V step() const { return V(a.t); }
+    // scalar indices for IF_DOMAIN conditions
+    template <int D>
+    __device__ __forceinline__ long long sidx() const { return D == 0 ? x + a.ofs_x : (D == 1 ? y + a.ofs_y : z + a.ofs_z); }
+    template <int D>
+    __device__ __forceinline__ long long first_idx() const { return 0; }
+    template <int D>
+    __device__ __forceinline__ long long last_idx() const { return D == 0 ? a.glast_x : (D == 1 ? a.glast_y : a.glast_z); }
+    __device__ __forceinline__ long long sstep() const { return a.t; }
 };
 
 template <class P>
@@ -155,6 +165,9 @@ __global__ void __launch_bounds__(256) naive_kernel(const PartArgs a) {
     int x = a.x0 + blockIdx.z;
     if (z >= a.z1 || y >= a.y1 || x >= a.x1) return;
     NaiveAcc<P> acc{a, x, y, z};
+    if constexpr (P::has_domain_cond) {
+        if (!P::cond(acc)) return;      // sub-domain parts: the predicate replaces the reference's BB lists
+    }
     P::eval(acc);
 }
 

@@ -69,6 +69,8 @@ struct PartMeta {
     int stage;                // owning stage
     bool has_domain_cond;
     bool has_step_cond;
+    bool is_scratch = false;                       // writes scratch vars: evaluated over the box grown by their halos
+    bool (*step_cond)(long long t) = nullptr;      // IF_STEP predicate (host); null = always
 };
 
 struct StageMeta {

@@ -264,6 +264,7 @@ public:
     idx_t local_size[MAX_DOMAIN_DIMS] = {0, 0, 0};   // computed rank-domain size
     std::vector<std::shared_ptr<Var>> vars;
     std::map<std::string, std::shared_ptr<Var>> var_map;
+    std::vector<std::shared_ptr<Var>> scratch_vars;   // compiler-declared scratch vars: device arrays, not in the API
     std::vector<int> part_variant;                   // chosen variant per part
     std::vector<idx_t> part_xchunk;
     hipStream_t compute_stream = nullptr, comm_stream = nullptr;

@@ -69,8 +69,8 @@ Solution::Solution(std::shared_ptr<Env> e, const SolnImpl& im) : env(e), impl(im
     }
     if (ndd > MAX_DOMAIN_DIMS) YKH_THROW("cdna4_hip runtime supports at most 3 domain dims");
     for (int v = 0; v < meta->n_vars; v++) {
-        if (meta->vars[v].is_scratch) continue;
         auto var = std::make_shared<Var>(this, &meta->vars[v], v);
+        if (meta->vars[v].is_scratch) { scratch_vars.push_back(var); continue; }   // (reference: one per thread, per block)
         vars.push_back(var);
         var_map[var->name] = var;
     }
@@ -86,6 +86,7 @@ Solution::Solution(std::shared_ptr<Env> e, const SolnImpl& im) : env(e), impl(im
 Solution::~Solution() {
     free_halo_buffers();
     vars.clear();
+    scratch_vars.clear();
     var_map.clear();
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
@@ -353,6 +354,7 @@ void Solution::prepare() {
         if (!same) v->allocate();
         v->set_dirty_all(true);
     }
+    for (auto& v : scratch_vars) { v->compute_geometry(); v->allocate(); v->l1_norm = 0; }
     free_halo_buffers();
     alloc_halo_buffers();
     // interior box for comm/compute overlap (alloc.cpp:686-723 `mpi_interior`)
@@ -395,6 +397,7 @@ void Solution::end() {
     synchronize();
     free_halo_buffers();
     for (auto& v : vars) v->release();
+    for (auto& v : scratch_vars) v->release();
     prepared = false;
 }
 
@@ -408,8 +411,20 @@ void Solution::fill_part_args(int part, idx_t t, const Box& box, PartArgs& a) co
         const AccessGroup& ag = pm.groups[g];
         const Var* v = nullptr;
         for (auto& vv : vars) if (vv->meta == &meta->vars[ag.var]) v = vv.get();
+        for (auto& vv : scratch_vars) if (vv->meta == &meta->vars[ag.var]) v = vv.get();
         if (!v || !v->is_allocated()) YKH_THROW("var used by part '" + std::string(pm.name) + "' has no storage");
-        a.ptr[g] = v->slot_base(ag.has_step ? t + ag.dt : 0);
+        char* base = (char*)v->slot_base(ag.has_step ? t + ag.dt : 0);
+        // constant misc indices of this access group
+        int mi = 0;
+        for (size_t p = 0; p < v->dims.size(); p++)
+            if (v->dims[p].type == DIM_MISC) {
+                idx_t mv = mi < ag.nmisc ? ag.misc[mi] : v->dims[p].first_misc;
+                if (mv < v->dims[p].first_misc || mv > v->dims[p].last_misc)
+                    YKH_THROW("misc index " + std::to_string(mv) + " of var '" + v->name + "' is outside its allocation");
+                base += (size_t)((mv - v->dims[p].first_misc) * v->misc_stride[p]) * elem_bytes();
+                mi++;
+            }
+        a.ptr[g] = base;
         a.gsx[g] = v->stride[0];
         a.gsy[g] = v->stride[1];
         a.gsz[g] = (int)v->stride[2];
@@ -429,6 +444,9 @@ void Solution::fill_part_args(int part, idx_t t, const Box& box, PartArgs& a) co
     a.y0 = (int)box.lo[1]; a.y1 = (int)box.hi[1];
     a.z0 = (int)box.lo[2]; a.z1 = (int)box.hi[2];
     a.ofs_x = (int)rank_ofs[0]; a.ofs_y = (int)rank_ofs[1]; a.ofs_z = (int)rank_ofs[2];
+    a.glast_x = (int)(ndd > 0 ? global_size[0] - 1 : 0);
+    a.glast_y = (int)(ndd > 1 ? global_size[1] - 1 : 0);
+    a.glast_z = (int)(ndd > 2 ? global_size[2] - 1 : 0);
     a.t = t;
 }
 
@@ -486,7 +504,24 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
 }
 
 void Solution::launch_part(int part, idx_t t, const Box& box, hipStream_t s) {
-    launch_part_variant(part, part_variant[part], part_xchunk[part], t, box, s);
+    const PartMeta& pm = *impl.parts[part].meta;
+    if (pm.step_cond && !pm.step_cond(t)) return;            // IF_STEP: the part is idle this step
+    if (!pm.is_scratch) { launch_part_variant(part, part_variant[part], part_xchunk[part], t, box, s); return; }
+    // scratch part: evaluate over the box grown by the halo of the scratch var(s) it writes, so that the
+    // parts reading them at offsets find every value (the reference does this per micro-block,
+    // src/kernel/lib/stencil_calc.cpp:40-289; here the scratch var is a whole device array)
+    Box b = box;
+    for (int w = 0; w < pm.n_writes; w++) {
+        const AccessGroup& ag = pm.groups[pm.writes[w]];
+        for (auto& v : scratch_vars)
+            if (v->meta == &meta->vars[ag.var])
+                for (int d = 0; d < ndd; d++)
+                    if (v->uses_domain[d]) {
+                        b.lo[d] = std::min(b.lo[d], box.lo[d] - v->halo_l[d]);
+                        b.hi[d] = std::max(b.hi[d], box.hi[d] + v->halo_r[d]);
+                    }
+    }
+    launch_part_variant(part, part_variant[part], part_xchunk[part], t, b, s);
 }
 
 // ------------------------------------------------------------------ run
@@ -535,6 +570,7 @@ void Solution::run(idx_t first_step, idx_t last_step) {
             // bookkeeping: written vars become valid at the output step and dirty for neighbours
             for (int k = 0; k < sm.n_parts; k++) {
                 const PartMeta& pm = *impl.parts[sm.parts[k]].meta;
+                if (pm.is_scratch || (pm.step_cond && !pm.step_cond(t))) continue;
                 for (int w = 0; w < pm.n_writes; w++) {
                     const AccessGroup& ag = pm.groups[pm.writes[w]];
                     for (auto& v : vars)
@@ -570,7 +606,10 @@ Stats Solution::get_stats() {
     for (int d = 0; d < ndd; d++) { pts *= global_size[d]; lpts *= local_size[d]; }
     s.num_elements = pts;
     idx_t reads = 0, writes = 0, fpops = 0;
-    for (auto& p : impl.parts) { reads += p.meta->points_read; writes += p.meta->points_written; fpops += p.meta->fp_ops; }
+    for (auto& p : impl.parts) {
+        if (p.meta->is_scratch) continue;      // the reference's work stats cover non-scratch parts
+        reads += p.meta->points_read; writes += p.meta->points_written; fpops += p.meta->fp_ops;
+    }
     s.num_writes_done = writes * pts * s.num_steps_done;
     s.num_reads_done = reads * pts * s.num_steps_done;
     s.est_fp_ops_done = fpops * pts * s.num_steps_done;
