@@ -247,6 +247,7 @@ public:
     bool overlap_comms = true;
     bool step_wrap = false;        // set_step_wrap(): any step index is accepted and wrapped onto the slots
     idx_t min_exterior = 0;
+    idx_t overlap_splits = 4;      // -hip_overlap_splits: interior launches per stage when overlapping comms
     bool do_halo_exchange = true;
     bool auto_tune = false;        // tuned at prepare() when true
     double auto_tune_trial_secs = 0.05;

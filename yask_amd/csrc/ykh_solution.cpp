@@ -77,7 +77,14 @@ Solution::Solution(std::shared_ptr<Env> e, const SolnImpl& im) : env(e), impl(im
     part_variant.assign(impl.parts.size(), -1);
     part_xchunk.assign(impl.parts.size(), 0);
     YKH_HIP(hipStreamCreateWithFlags(&compute_stream, hipStreamNonBlocking));
-    YKH_HIP(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+    {
+        // halo traffic gets the highest stream priority: its small pack/RCCL/unpack kernels are dispatched
+        // ahead of queued stencil workgroups whenever a CU frees up
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
+        if (hipStreamCreateWithPriority(&comm_stream, hipStreamNonBlocking, hi) != hipSuccess)
+            YKH_HIP(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+    }
     own_streams = true;
     YKH_HIP(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
     YKH_HIP(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
@@ -172,7 +179,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                                "bind_inner_threads", "bundle_allocs", "init_scratch_vars", "auto_tune",
                                "allow_addl_padding", "round_up_temporal_angles", "print_suffixes", "verbose",
                                "exchange_halos", "auto_tune_each_stage", "trace"};
-    const char* int_opts[] = {"min_exterior", "max_threads", "outer_threads", "inner_threads", "numa_pref",
+    const char* int_opts[] = {"hip_overlap_splits", "min_exterior", "max_threads", "outer_threads", "inner_threads", "numa_pref",
                               "auto_tune_radius", "thread_divisor", "block_threads", "hip_xchunk", "device_thread_limit"};
     const char* dbl_opts[] = {"auto_tune_trial_secs"};
     const char* str_opts[] = {"auto_tune_targets", "hip_variant"};
@@ -210,6 +217,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                 handled = true;
                 if (opt == "min_exterior") min_exterior = n;
                 else if (opt == "hip_xchunk") xchunk_override = n;
+                else if (opt == "hip_overlap_splits") overlap_splits = std::max<idx_t>(1, n);
                 else ignored_opts[opt] = v;
             }
         if (handled) continue;
@@ -582,8 +590,20 @@ void Solution::run(idx_t first_step, idx_t last_step) {
             }
             if (multi) {
                 exchange_halos(t, st, /*start_only=*/true, false);
-                if (overlap)
-                    for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, interior_box, compute_stream);
+                if (overlap) {
+                    // The marching kernels keep one workgroup per CU resident for a whole launch, so a single
+                    // interior launch would leave no CU for the comm stream until it ends.  Split the interior
+                    // along x into a few back-to-back launches: at each boundary CUs drain and the (higher
+                    // priority) pack / send-recv / unpack kernels get in.
+                    const idx_t nxi = interior_box.hi[0] - interior_box.lo[0];
+                    const idx_t nsplit = std::max<idx_t>(1, std::min<idx_t>(overlap_splits, nxi / 64));
+                    for (idx_t c = 0; c < nsplit; c++) {
+                        Box b = interior_box;
+                        b.lo[0] = interior_box.lo[0] + nxi * c / nsplit;
+                        b.hi[0] = interior_box.lo[0] + nxi * (c + 1) / nsplit;
+                        for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, b, compute_stream);
+                    }
+                }
                 exchange_halos(t, st, false, /*finish_only=*/true);
             }
         }
