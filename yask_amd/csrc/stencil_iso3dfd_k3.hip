@@ -9,6 +9,5 @@ void iso3dfd_variants_k3(PartImpl& p) {
     p.variants.push_back(starlin_variant<part_1, 2, 64, 16, 1, ROT_MOVE, 1, 4, 8, 0>());
     p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 1, ROT_MOVE, 1, 4, 8, 0>());
     p.variants.push_back(starlin_variant<part_1, 4, 64, 4, 1, ROT_MOVE, 1, 3, 4, 0>());
-    p.variants.push_back(starlin_variant<part_1, 4, 32, 8, 1, ROT_UNROLL, 1, 2, 4, 0>());
 }
 }  // namespace ykh

@@ -132,11 +132,28 @@ struct LinAcc {
 };
 
 template <class V, typename T> __device__ __forceinline__ V ldv(const T* p) { return *reinterpret_cast<const V*>(p); }
+// uniform base + 32-bit unsigned byte offset (selects the saddr form of global_load/store)
+template <class V, typename T> __device__ __forceinline__ V ldv_b(const T* base, unsigned byte_off) {
+    return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + byte_off); }
+template <class V, typename T> __device__ __forceinline__ void stv_b(T* base, unsigned byte_off, V v) {
+    *reinterpret_cast<V*>(reinterpret_cast<char*>(base) + byte_off) = v; }
+template <class V, typename T> __device__ __forceinline__ void stv_b_nt(T* base, unsigned byte_off, V v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<V*>(reinterpret_cast<char*>(base) + byte_off)); }
+template <class V, typename T> __device__ __forceinline__ V ldv_b_nt(const T* base, unsigned byte_off) {
+    return __builtin_nontemporal_load(reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + byte_off)); }
 template <class V, typename T> __device__ __forceinline__ void stv(T* p, V v) { *reinterpret_cast<V*>(p) = v; }
 template <class V, typename T> __device__ __forceinline__ V ldv_nt(const T* p) { return __builtin_nontemporal_load(reinterpret_cast<const V*>(p)); }
 template <class V, typename T> __device__ __forceinline__ void stv_nt(T* p, V v) { __builtin_nontemporal_store(v, reinterpret_cast<V*>(p)); }
 
-// NTH : 1 = non-temporal loads of centre-only operands and non-temporal stores.
+// NTH : bit 0 = non-temporal loads of centre-only operands and non-temporal stores;
+//       bits 1-2 = when the halo vectors of the next plane are requested: 0 with its interior (before the
+//       barrier), 1 after the first row of the current plane has been computed, 2 at the end of the
+//       iteration.  Later = the neighbour tiles' interior loads of the same lines have reached L2 first.
+//       bit 3 = prefetch the star-group planes TWO planes ahead (two alternating register sets): with one
+//       workgroup per CU the loop is latency-bound (one plane of loads in flight per iteration), depth 2
+//       doubles the bytes in flight for 16 more VGPRs.
+//       bit 4 = likewise load the centre-only operands (two thirds of the read bytes of iso3dfd) two output
+//       planes ahead.
 // MINW: minimum resident waves per SIMD the register allocation must allow (k blocks of T threads per
 //       CU <=> k*T/256), MI355X_MICROARCH.md "Register files".
 // ABL (profiling only): 1 = no halo loads, 2 = no centre-operand loads, 4 = no stores.
@@ -148,6 +165,12 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
     constexpr int NP = C::NP, NA = C::NA, XL = C::XL, XH = C::XH, YL = C::YL;
     constexpr int ZLV = C::ZLV, ZHV = C::ZHV, LP = C::LP, NT = C::NT, NHT = C::NHT, NY = C::NY;
     constexpr int SG = C::SG, NG = P::n_groups;
+    constexpr bool NT_STREAMS = (NTH & 1) != 0;
+    constexpr int HALO_LATE = (NTH >> 1) & 3;
+    constexpr int PD = ((NTH >> 3) & 1) ? 2 : 1;      // prefetch depth in planes
+    constexpr int CD = ((NTH >> 4) & 1) ? 2 : 1;      // prefetch depth of the centre-only operands
+    constexpr int TRIP = (PD > CD) ? PD : CD;         // planes per loop trip (register sets alternate)
+    static_assert(CD == 1 || XH > 0, "operand prefetch depth 2 needs a future x range");
     static_assert(!C::R.mixed, "linear form has a mixed-offset term");
     static_assert(NG <= MAX_GROUPS, "too many access groups");
     static_assert(VZ * sizeof(T) <= 16, "z-vector wider than 16 bytes");
@@ -176,14 +199,17 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
     const int zc = clampi(myz, a.az0, a.az1 - VZ);
     const T* __restrict__ sp = (const T*)a.ptr[SG];
 
-    // plane-relative element offsets (int: a plane has < 2^31 elements)
-    int roff[RY];
+    // Plane-relative element offsets, measured from the first allocated element of a plane so that they
+    // are non-negative 32-bit numbers: global accesses then use the scalar-base + 32-bit-offset
+    // addressing form (one VGPR per address instead of two, no 64-bit vector adds).
+    const idx_t org = (idx_t)a.ay0 * a.sy + a.az0;          // offset of the plane's first allocated element
+    unsigned roff[RY];
     static_for<RY>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         int y = clampi(yt0 + ly * RY + j, a.ay0, a.ay1 - 1);
-        roff[j] = y * (int)a.sy + zc;
+        roff[j] = (unsigned)((y - a.ay0) * (int)a.sy + (zc - a.az0)) * (unsigned)sizeof(T);   // bytes
     });
-    int hoff[NHT > 0 ? NHT : 1];
+    unsigned hoff[NHT > 0 ? NHT : 1];
     int hlds[NHT > 0 ? NHT : 1];
     static_for<NHT>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
@@ -203,38 +229,44 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
         if (h >= C::NH) { row = 0; zv = 0; }
         int y = clampi(yt0 - YL + row, a.ay0, a.ay1 - 1);
         int z = clampi(zt0 - ZLV * VZ + zv * VZ, a.az0, a.az1 - VZ);
-        hoff[k] = y * (int)a.sy + z;
+        hoff[k] = (unsigned)((y - a.ay0) * (int)a.sy + (z - a.az0)) * (unsigned)sizeof(T);   // bytes
         hlds[k] = (h < C::NH) ? row * LP + zv * VZ : -1;
     });
 
-    auto xplane = [&](int x) -> idx_t { return (idx_t)clampi(x, a.ax0, a.ax1 - 1) * a.sx; };
+    auto xplane = [&](int x) -> idx_t { return (idx_t)clampi(x, a.ax0, a.ax1 - 1) * a.sx + org; };
 
     V pq[NP][RY];
     V acc[NA][RY];
-    V nxt[RY];
-    V hreg[NHT > 0 ? NHT : 1];
-    V cen[NG][RY];     // centre-only operands of the next output plane (one set, refilled after use)
+    V nxt[PD][RY];
+    V hreg[PD][NHT > 0 ? NHT : 1];
+    V cen[CD][NG][RY];     // centre-only operands of the next CD output planes (refilled after use)
 
-    auto load_centres = [&](idx_t pc) {
+    auto load_centres = [&](idx_t pc, auto cs) {
+        constexpr int CS = decltype(cs)::value;
         static_for<NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             if constexpr (g != SG && analyze_group<P>(g).any) {
                 const T* gp = (const T*)a.ptr[g] + pc;
                 static_for<RY>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
-                    if constexpr (ABL & 2) cen[g][j] = V(1);
-                    else if constexpr (NTH) cen[g][j] = ldv_nt<V>(gp + roff[j]);
-                    else cen[g][j] = ldv<V>(gp + roff[j]);
+                    if constexpr (ABL & 2) cen[CS][g][j] = V(1);
+                    else if constexpr (NT_STREAMS) cen[CS][g][j] = ldv_b_nt<V>(gp, roff[j]);
+                    else cen[CS][g][j] = ldv_b<V>(gp, roff[j]);
                 });
             }
         });
     };
-    auto load_plane = [&](int x) {
+    auto load_interior = [&](int x, auto sc) {
+        constexpr int S = decltype(sc)::value;
         const T* pp = sp + xplane(x);
-        static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; nxt[j] = ldv<V>(pp + roff[j]); });
+        static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; nxt[S][j] = ldv_b<V>(pp, roff[j]); });
+    };
+    auto load_halo = [&](int x, auto sc) {
+        constexpr int S = decltype(sc)::value;
+        const T* pp = sp + xplane(x);
         static_for<NHT>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            if constexpr (ABL & 1) hreg[k] = V(0); else hreg[k] = ldv<V>(pp + hoff[k]);
+            if constexpr (ABL & 1) hreg[S][k] = V(0); else hreg[S][k] = ldv_b<V>(pp, hoff[k]);
         });
     };
 
@@ -243,18 +275,25 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
     static_for<NP - 1>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const T* pp = sp + xplane(xs - (NP - 1) + i);
-        static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; pq[i][j] = ldv<V>(pp + roff[j]); });
+        static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; pq[i][j] = ldv_b<V>(pp, roff[j]); });
     });
     static_for<NA>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; acc[i][j] = V(0); });
     });
-    load_plane(xs);
-    if constexpr (XH == 0) load_centres(xplane(xs));
+    static_for<PD>([&](auto sc) { load_interior(xs + decltype(sc)::value, sc); load_halo(xs + decltype(sc)::value, sc); });
+    if constexpr (XH == 0) load_centres(xplane(xs), std::integral_constant<int, 0>{});
 
     // One arriving plane. PH renames the queue slots when the loop is unrolled PERIOD times.
-    auto plane = [&](int xin, auto ph_tag) {
+    // `set_tag`: which prefetch register set holds the arriving plane (PD == 2: the plane's parity).
+    // `trip_tag`: position of the plane within a loop trip; selects the alternating register sets.
+    auto plane = [&](int xin, auto ph_tag, auto trip_tag) {
         constexpr int PH = decltype(ph_tag)::value;
+        constexpr int S = decltype(trip_tag)::value % PD;
+        constexpr int CS = decltype(trip_tag)::value % CD;
+        typedef std::integral_constant<int, S> set_t;
+        typedef std::integral_constant<int, CS> cset_t;
+        const set_t set_tag{};
         constexpr int qn = rot<NP>(PH, NP - 1), an = rot<NA>(PH, NA - 1);
         constexpr int qo = rot<NP>(PH, NP - 1 - XH), ao = rot<NA>(PH, 0);
         T* sb;
@@ -263,15 +302,16 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
         const int xo = xin - XH;
         static_for<RY>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            pq[qn][j] = nxt[j];
-            stv<V>(sb + (YL + ly * RY + j) * LP + (ZLV + lz) * VZ, nxt[j]);
+            pq[qn][j] = nxt[S][j];
+            stv<V>(sb + (YL + ly * RY + j) * LP + (ZLV + lz) * VZ, nxt[S][j]);
         });
         static_for<NHT>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            if (hlds[k] >= 0) stv<V>(sb + hlds[k], hreg[k]);
+            if (hlds[k] >= 0) stv<V>(sb + hlds[k], hreg[S][k]);
         });
         // prefetch the next arriving plane (registers of nxt/hreg are free again)
-        load_plane(xin + 1);
+        load_interior(xin + PD, set_tag);
+        if constexpr (HALO_LATE == 0) load_halo(xin + PD, set_tag);
         __syncthreads();
 
         const T* colp = sb + (ZLV + lz) * VZ;
@@ -349,48 +389,56 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
             V cj[MAX_GROUPS], out[MAX_GROUPS];
             static_for<NG>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
-                if constexpr (g != SG && analyze_group<P>(g).any) cj[g] = cen[g][j];
+                if constexpr (g != SG && analyze_group<P>(g).any) cj[g] = cen[CS][g][j];
             });
             LinAcc<C> la{pq[qo][j], cj, out};
             P::eval_lin(la, acc[ao][j]);
             const int y = yt0 + ly * RY + j;
             if (xo >= xs && xo < xe && y < a.y1 && myz < a.z1 && myz + VZ > a.z0) {
-                const idx_t o = (idx_t)xo * a.sx + (idx_t)y * a.sy + myz;
+                // points inside the box are never clamped, so roff[j] is also the store offset
                 static_for<P::n_writes>([&](auto wc) {
                     constexpr int g = P::writes[decltype(wc)::value];
-                    T* op = (T*)a.ptr[g] + o;
-                    if constexpr (ABL & 4) { if (out[g][0] == T(123.456)) op[0] = out[g][0]; }
+                    T* ob = (T*)a.ptr[g] + ((idx_t)xo * a.sx + org);          // uniform
+                    if constexpr (ABL & 4) { if (out[g][0] == T(123.456)) ob[0] = out[g][0]; }
                     else if (myz >= a.z0 && myz + VZ <= a.z1) {
-                        if constexpr (NTH) stv_nt<V>(op, out[g]); else stv<V>(op, out[g]);
-                    } else
+                        if constexpr (NT_STREAMS) stv_b_nt<V>(ob, roff[j], out[g]); else stv_b<V>(ob, roff[j], out[g]);
+                    } else {
+                        T* op = reinterpret_cast<T*>(reinterpret_cast<char*>(ob) + roff[j]);
                         static_for<VZ>([&](auto ec) {
                             constexpr int e = decltype(ec)::value;
                             if (myz + e >= a.z0 && myz + e < a.z1) op[e] = out[g][e];
                         });
+                    }
                 });
             }
+            if constexpr (HALO_LATE == 1 && j == 0) load_halo(xin + PD, set_tag);
         });
+        if constexpr (HALO_LATE == 2) load_halo(xin + PD, set_tag);
         // operands of the next output plane: a whole plane of work hides their latency
-        if (xo + 1 >= xs && xo + 1 < xe) load_centres((idx_t)(xo + 1) * a.sx);
+        if (xo + CD >= xs && xo + CD < xe) load_centres((idx_t)(xo + CD) * a.sx + org, cset_t{});
     };
 
+    auto rotate = [&]() {
+        static_for<NP - 1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; pq[i][j] = pq[i + 1][j]; });
+        });
+        static_for<NA - 1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; acc[i][j] = acc[i + 1][j]; });
+        });
+    };
+    typedef std::integral_constant<int, 0> I0;
     if constexpr (ROT == ROT_MOVE) {
-        for (int x = xs; x < xlast; x++) {
-            plane(x, std::integral_constant<int, 0>{});
-            static_for<NP - 1>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; pq[i][j] = pq[i + 1][j]; });
-            });
-            static_for<NA - 1>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; acc[i][j] = acc[i + 1][j]; });
-            });
-        }
+        // PD planes per trip (the prefetch sets alternate); a trip may run past xlast-1: loads are clamped
+        // to the allocation and stores are predicated on xo < xe.
+        for (int x = xs; x < xlast; x += TRIP)
+            static_for<TRIP>([&](auto sc) { plane(x + decltype(sc)::value, I0{}, sc); rotate(); });
     } else {
-        // UNR planes per trip (queue rotation by renaming); the last trip may run past xlast-1:
-        // loads are clamped to the allocation and stores are predicated on xo < xe.
+        // UNR planes per trip (queue rotation by renaming); the last trip may run past xlast-1.
+        static_assert(TRIP == 1 || C::UNR % 2 == 0, "prefetch depth 2 needs an even unroll count");
         for (int x = xs; x < xlast; x += C::UNR)
-            static_for<C::UNR>([&](auto phc) { plane(x + decltype(phc)::value, phc); });
+            static_for<C::UNR>([&](auto phc) { plane(x + decltype(phc)::value, phc, phc); });
     }
 }
 
