@@ -34,6 +34,7 @@ WORKLOADS = {
     "iso3dfd": ("iso3dfd", "iso3dfd r=8 fp32", 1024, "f32", 16.0, {"p": (0.0, 1.0, 0), "v": (150.0, 50.0, 1)}),
     # configs[2]: read 8 + write 8
     "3axis": ("3axis", "3axis r=4 fp64", 512, "f64", 16.0, {"A": (0.0, 1.0, 0)}),
+    "heat3d": ("3axis_r1", "3axis r=1 (classic 7-point heat3d) fp64", 512, "f64", 16.0, {"A": (0.0, 1.0, 0)}),
     # configs[4]: stage 1 (10 reads + 3 writes) + stage 2 (12 reads + 6 writes), 4 B each
     "ssg": ("ssg", "ssg staggered-grid elastic fp32 (2 stages)", 512, "f32", 124.0,
             {**{f: (0.0, 1.0e-3, i + 1) for i, f in enumerate(["v_bl_w", "v_tl_v", "v_tr_u", "s_bl_yz", "s_br_xz", "s_tl_xx",

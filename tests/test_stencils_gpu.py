@@ -84,6 +84,26 @@ def test_axis3_constant_field_is_a_fixed_point(gpu):
     assert np.abs(got - 3.25).max() <= 1e-13
 
 
+def test_axis3_radius1_heat3d_every_variant_matches_oracle(gpu):
+    """BASELINE config 3 calls the fp64 case "heat3d": the classic 7-point stencil is AxisStencil at radius 1."""
+    size, steps = (19, 33, 66), 4
+    ref = O.run_axis3(size, steps, radius=1)
+    from yask_amd import yk_factory
+    fac = yk_factory("3axis_r1")
+    names = [n for n in fac.new_solution(fac.new_env()).get_kernel_variant_names(0) if not n.startswith("abl")]
+    for name in names:
+        soln = fac.new_solution(fac.new_env())
+        soln.set_overall_domain_size_vec(list(size))
+        assert soln.apply_command_line_options(f"-hip_variant {name}") == ""
+        soln.prepare_solution()
+        A = soln.get_var("A")
+        assert A.get_left_halo_size("x") == 1 and A.get_right_halo_size("z") == 1
+        A.set_elements_hash(0.0, 1.0, hash_id=0)
+        soln.run_solution(0, steps - 1)
+        err = O.rel_linf(domain_slice(soln, A, steps), ref[("A", steps)])
+        assert err <= 1e-12, (name, err)
+
+
 # ------------------------------------------------------------------ ssg fp32
 def _ssg_err(soln, ref, steps):
     worst = 0.0

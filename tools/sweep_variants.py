@@ -33,8 +33,9 @@ def main():
         s.set_overall_domain_size_vec(size)
         s.prepare_solution()
         for v in s.get_vars():
-            off, sc = O.DEFAULT_INIT[args.stencil][v.get_name()]
-            v.set_elements_hash(off, sc, hash_id=O.VAR_IDS[args.stencil][v.get_name()])
+            key = args.stencil if args.stencil in O.DEFAULT_INIT else args.stencil.split("_r")[0]
+            off, sc = O.DEFAULT_INIT.get(key, {}).get(v.get_name(), (1.5, 0.5))
+            v.set_elements_hash(off, sc, hash_id=O.VAR_IDS.get(key, {}).get(v.get_name(), 0))
         return s
 
     soln = make()

@@ -1,0 +1,27 @@
+// stencil_3axis.hip -- kernel registry of solution '3axis' at radius 1 (the classic 7-point heat stencil, fp64: the
+// "heat3d"-like double-precision bandwidth validation case; DSL: src/stencils/SimpleStencils.cpp:39-115
+// of the reference).  Links with the generic runtime into libyask_kernel.3axis.cdna4_hip.so.
+#include "gen/3axis_r1_cdna4_hip.hpp"
+#include "ykh_stencil_tu.hpp"
+
+namespace ykh {
+void s3axis_r1_variants_k1(PartImpl&);
+void s3axis_r1_variants_k2(PartImpl&);
+
+const SolnImpl& ykh_solution_impl() {
+    using namespace ykh_gen_3axis;
+    static const SolnImpl impl = [] {
+        SolnImpl s;
+        s.meta = &soln;
+        PartImpl p;
+        p.meta = &parts[0];
+        p.variants.push_back(naive_variant<part_1>());
+        s3axis_r1_variants_k1(p);
+        s3axis_r1_variants_k2(p);
+        p.set_default("starlin_v2_z128_y32_r4_m_nt_w2_c4");
+        s.parts.push_back(p);
+        return s;
+    }();
+    return impl;
+}
+}  // namespace ykh

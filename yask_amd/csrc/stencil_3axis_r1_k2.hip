@@ -1,0 +1,12 @@
+// stencil_3axis_k2.hip -- more tile shapes for '3axis'.
+#include "gen/3axis_r1_cdna4_hip.hpp"
+#include "ykh_stencil_tu.hpp"
+namespace ykh {
+using namespace ykh_gen_3axis;
+void s3axis_r1_variants_k2(PartImpl& p) {
+    p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_MOVE, 1, 2, 4>());
+    p.variants.push_back(starlin_variant<part_1, 2, 64, 16, 1, ROT_MOVE, 1, 4, 4>());
+    p.variants.push_back(starlin_variant<part_1, 2, 32, 16, 2, ROT_UNROLL, 1, 2, 4>());
+    p.variants.push_back(starlin_variant<part_1, 2, 32, 16, 2, ROT_MOVE, 0, 2, 4>());
+}
+}  // namespace ykh

@@ -300,6 +300,12 @@ class yk_solution:
         self._lib.call_rc("yk_solution_get_stats", self._h, C.byref(st))
         return yk_stats(st)
 
+    def clear_stats(self): self._lib.call_rc("yk_solution_clear_stats", self._h)
+    def set_min_pad_size(self, dim, n): self._lib.call_rc("yk_solution_set_min_pad_size", self._h, _b(dim), n)
+    def get_min_pad_size(self, dim): return self._lib.call("yk_solution_get_min_pad_size", self._h, _b(dim))
+    def set_step_wrap(self, do_wrap): self._lib.call_rc("yk_solution_set_step_wrap", self._h, int(bool(do_wrap)))
+    def get_step_wrap(self): return bool(self._lib.call("yk_solution_get_step_wrap", self._h))
+
     def reset_auto_tuner(self, enable, verbose=False): self._lib.call_rc("yk_solution_reset_auto_tuner", self._h, int(enable), int(verbose))
     def is_auto_tuner_enabled(self): return bool(self._lib.call("yk_solution_is_auto_tuner_enabled", self._h))
     def run_auto_tuner_now(self, verbose=True): self._lib.call_rc("yk_solution_run_auto_tuner_now", self._h, int(verbose))
