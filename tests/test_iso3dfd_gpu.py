@@ -129,3 +129,25 @@ def test_linearity_at_full_width_rows(gpu):
         outs.append(domain_slice(soln, p, steps).astype(np.float64))
     err = np.abs(outs[0] + outs[1] - outs[2]).max() / max(1.0, np.abs(outs[2]).max())
     assert err <= 1e-5, err
+
+
+def test_full_size_1024_properties(gpu):
+    """BASELINE.json configs[1] size (1024^3, ~15 GB per solution), size-independent properties:
+    (a) the tuned kernel agrees with the generic point kernel everywhere (reference rule, eps 1e-4 << 1e-3);
+    (b) a constant wavefield is a fixed point for any velocity model (the FD weights sum to zero)."""
+    n, steps = 1024, 2
+    _, _, a = make((n, n, n))
+    assert a.get_kernel_variant(0).startswith("starlin")
+    _, _, b = make((n, n, n), "-force_scalar")
+    assert b.get_kernel_variant(0) == "naive"
+    a.run_solution(0, steps - 1)
+    b.run_solution(0, steps - 1)
+    assert a.compare_data(b, 1e-4) == 0
+    b.end_solution()
+    p = a.get_var("p")
+    p.set_all_elements_same(0.75)
+    a.run_solution(steps, steps + 2)
+    r = p.reduce_elements_in_slice(8 | 16, [steps + 3, 0, 0, 0], [steps + 3, n - 1, n - 1, n - 1])
+    assert abs(r.get_max() - 0.75) <= 2e-6 and abs(r.get_min() - 0.75) <= 2e-6
+    assert r.get_num_elements_reduced() == n ** 3
+    a.end_solution()

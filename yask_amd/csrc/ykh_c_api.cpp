@@ -579,7 +579,10 @@ int yk_var_fuse_vars(yk_var_h v, yk_var_h src) {
     if (!yk_var_is_storage_layout_identical(v, src)) YKH_THROW("fuse_vars: storage layouts of '" + a->name + "' and '" + b->name + "' differ");
     if (!b->is_allocated()) { a->release(); return 0; }
     if (!a->is_allocated()) a->allocate();
-    YKH_HIP(hipMemcpy(a->dptr, b->dptr, a->bytes(), hipMemcpyDeviceToDevice));
+    // ordered after everything queued on either solution's stream, and complete on return
+    YKH_HIP(hipStreamSynchronize(b->soln->compute_stream));
+    YKH_HIP(hipMemcpyAsync(a->dptr, b->dptr, a->bytes(), hipMemcpyDeviceToDevice, a->soln->compute_stream));
+    YKH_HIP(hipStreamSynchronize(a->soln->compute_stream));
     a->first_valid_step = b->first_valid_step;
     a->set_dirty_all(true);
     return 0;

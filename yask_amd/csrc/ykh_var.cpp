@@ -147,7 +147,11 @@ void Var::allocate() {
     size_t nb = bytes();
     if (nb == 0) nb = 256;
     YKH_HIP(hipMalloc(&dptr, nb));
-    YKH_HIP(hipMemset(dptr, 0, nb));
+    // Zero on the solution's own stream: hipMemset() runs on the NULL stream, which the solution's
+    // non-blocking streams do not synchronise with -- a multi-GB memset was still clearing the tail of the
+    // allocation while the first init kernel had already written it (seen at >= 512^3).
+    YKH_HIP(hipMemsetAsync(dptr, 0, nb, soln->compute_stream));
+    YKH_HIP(hipStreamSynchronize(soln->compute_stream));
     mirror_.clear();
     mirror_valid_ = false;
 }
@@ -529,13 +533,15 @@ void* Var::host_mirror() {
     if (!dptr) return nullptr;
     if (mirror_.size() != bytes()) mirror_.assign(bytes(), 0);
     YKH_HIP(hipStreamSynchronize(soln->compute_stream));
-    YKH_HIP(hipMemcpy(mirror_.data(), dptr, bytes(), hipMemcpyDeviceToHost));
+    YKH_HIP(hipMemcpyAsync(mirror_.data(), dptr, bytes(), hipMemcpyDeviceToHost, soln->compute_stream));
+    YKH_HIP(hipStreamSynchronize(soln->compute_stream));
     mirror_valid_ = true;
     return mirror_.data();
 }
 void Var::sync_mirror_to_device() {
     if (!dptr || mirror_.size() != bytes()) return;
-    YKH_HIP(hipMemcpy(dptr, mirror_.data(), bytes(), hipMemcpyHostToDevice));
+    YKH_HIP(hipMemcpyAsync(dptr, mirror_.data(), bytes(), hipMemcpyHostToDevice, soln->compute_stream));
+    YKH_HIP(hipStreamSynchronize(soln->compute_stream));
     set_dirty_all(true);
 }
 
