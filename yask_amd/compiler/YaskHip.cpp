@@ -111,7 +111,7 @@ namespace yask {
                 auto it = memo.find(key);
                 if (it != memo.end()) return it->second;
                 string n = "e" + to_string(++ntemps);
-                body << "        V " << n << " = " << rhs << ";\n";
+                body << "        V " << n << " = " << rhs << "; a.pin(" << n << ");\n";
                 memo[key] = n;
                 return n;
             }

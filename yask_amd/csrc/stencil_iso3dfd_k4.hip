@@ -10,6 +10,8 @@ void iso3dfd_variants_k4(PartImpl& p) {
     p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 5, 2, 4, 0>());   // halos at the end
     p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 1, ROT_MOVE, 25, 2, 4, 0>());   // 128x16 tile, everything 2 ahead
     p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 1, ROT_MOVE, 9, 2, 4, 0>());    // 128x16 tile, depth 2
+    // 256-thread workgroups, two per CU: independent barriers, one computes while the other waits on memory
+    p.variants.push_back(starlin_variant<part_1, 4, 32, 8, 2, ROT_MOVE, 1, 2, 4, 0>());    // tile 128x16
     p.variants.push_back(starlin_variant<part_1, 4, 64, 8, 2, ROT_MOVE, 1, 2, 4, 0>());
     p.variants.push_back(starlin_variant<part_1, 4, 16, 32, 2, ROT_MOVE, 1, 2, 4, 0>());
 }

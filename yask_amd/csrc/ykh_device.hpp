@@ -144,6 +144,7 @@ struct NaiveAcc {
         T* p = (T*)a.ptr[G];
         p[(idx_t)x * a.gsx[G] + (idx_t)y * a.gsy[G] + (idx_t)z * a.gsz[G]] = v;
     }
+    __device__ __forceinline__ void pin(V&) const {}   // scheduling hint of the generated code (see MarchAcc)
     // global index of the point in domain dim D / the evaluation step, as values
     template <int D>
     __device__ __forceinline__ V idx() const { return V(D == 0 ? x + a.ofs_x : (D == 1 ? y + a.ofs_y : z + a.ofs_z)); }
@@ -240,6 +241,7 @@ struct StarAcc {
     }
     template <int G>
     __device__ __forceinline__ void wr(V v) { out[G] = v; }
+    __device__ __forceinline__ void pin(V&) const {}
 };
 
 template <typename T>

@@ -56,11 +56,11 @@ struct MarchTab {
     int nhy[MAX_GROUPS], nh[MAX_GROUPS], nht[MAX_GROUPS], hoff[MAX_GROUPS + 1];
 };
 
-template <class P, int VZ_, int TZL_, int TYL_>
+template <class P, int VZ_, int TZL_, int TYL_, int RY_ = 1>
 struct MarchCfg {
     typedef typename P::real_t T;
-    static constexpr int VZ = VZ_, TZL = TZL_, TYL = TYL_, NT = TZL_ * TYL_, NG = P::n_groups;
-    static constexpr int TZ = TZL * VZ, TY = TYL;
+    static constexpr int VZ = VZ_, TZL = TZL_, TYL = TYL_, RY = RY_, NT = TZL_ * TYL_, NG = P::n_groups;
+    static constexpr int TZ = TZL * VZ, TY = TYL * RY;      // RY rows per thread
     static constexpr MarchTab make() {
         MarchTab t = {};
         int qo = 0, so = 0, ho = 0;
@@ -90,15 +90,17 @@ struct MarchCfg {
     static constexpr size_t lds_bytes = sizeof(T) * 2 * (SLAB_TOT > 0 ? SLAB_TOT : 1);
 };
 
-template <class C, class P>
+// PIN: honour the generated code's pin() after every temporary (strict program order: smallest live
+// ranges, least instruction-level parallelism); otherwise only the equations are kept sequential.
+template <class C, class P, bool PIN = false>
 struct MarchAcc {
     typedef typename C::T T;
     typedef typename vecn<T, C::VZ>::type V;
     static constexpr int VZ = C::VZ;
     const PartArgs& a;
-    const V (&q)[C::NQTOT > 0 ? C::NQTOT : 1];
+    const V (&q)[C::NQTOT > 0 ? C::NQTOT : 1];     // queues of the row being evaluated
     const T* sb;            // current slab buffer set
-    int ly, lz;             // thread position in the tile
+    int ly, lz;             // row (within the tile) and z lane of the point
     int x, y, z0;           // point (first of the VZ)
     V (&out)[MAX_GROUPS];
     template <int G, int DX, int DY, int DZ>
@@ -131,6 +133,7 @@ struct MarchAcc {
     // reads of all equations to the top of eval() and the live values exceed the register file.
     template <int G>
     __device__ __forceinline__ void wr(V v) { out[G] = v; asm volatile("" : "+v"(out[G]) : : "memory"); }
+    __device__ __forceinline__ void pin(V& v) const { if constexpr (PIN) asm volatile("" : "+v"(v) : : "memory"); }
     template <int D>
     __device__ __forceinline__ V idx() const {
         if constexpr (D == 2) { V r; static_for<VZ>([&](auto ec) { constexpr int e = decltype(ec)::value; r[e] = T(z0 + e + a.ofs_z); }); return r; }
@@ -139,9 +142,9 @@ struct MarchAcc {
     __device__ __forceinline__ V step() const { return V(T(a.t)); }
 };
 
-template <class P, int VZ, int TZL, int TYL, int MINW>
+template <class P, int VZ, int TZL, int TYL, int MINW, int RY = 1, bool PIN = false>
 __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a) {
-    typedef MarchCfg<P, VZ, TZL, TYL> C;
+    typedef MarchCfg<P, VZ, TZL, TYL, RY> C;
     typedef typename C::T T;
     typedef typename vecn<T, VZ>::type V;
     constexpr int NG = C::NG, NT = C::NT;
@@ -164,10 +167,12 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
     const int xe = (xs + a.xchunk < a.x1) ? xs + a.xchunk : a.x1;
     if (xs >= xe) return;
     const int myz = zt0 + lz * VZ;
-    const int myy = yt0 + ly;
+    const int myy0 = yt0 + ly * RY;       // first of this thread's RY rows
 
-    // own-point offset within a plane, per group (vars lacking a dim have stride 0), clamped into the allocation
-    const int yc = clampi(myy, a.ay0, a.ay1 - 1), zc = clampi(myz, a.az0, a.az1 - VZ);
+    // own-point offsets within a plane (vars lacking a dim have stride 0), clamped into the allocation
+    int yc[RY];
+    static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; yc[j] = clampi(myy0 + j, a.ay0, a.ay1 - 1); });
+    const int zc = clampi(myz, a.az0, a.az1 - VZ);
     auto xclamp = [&](int x) { return clampi(x, a.ax0, a.ax1 - 1); };
 
     // halo assignments: for group g, halo vector h = tid + k*NT
@@ -203,14 +208,14 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
         }
     });
 
-    V q[C::NQTOT > 0 ? C::NQTOT : 1];
-    V nxt[NG];
+    V q[RY][C::NQTOT > 0 ? C::NQTOT : 1];
+    V nxt[RY][NG];
     V hreg[C::NHTOT > 0 ? C::NHTOT : 1];
 
-    // load the own-point vector of group g at plane x (vars without z: broadcast)
-    auto ld_own = [&](auto gc, int x) -> V {
+    // load the own-point vector of group g, row j, at plane x (vars without z: broadcast)
+    auto ld_own = [&](auto gc, int j, int x) -> V {
         constexpr int g = decltype(gc)::value;
-        const T* p = (const T*)a.ptr[g] + (idx_t)xclamp(x) * a.gsx[g] + (idx_t)yc * a.gsy[g];
+        const T* p = (const T*)a.ptr[g] + (idx_t)xclamp(x) * a.gsx[g] + (idx_t)yc[j] * a.gsy[g];
         if (a.gsz[g] == 0) return V(p[0]);
         return ldv<V>(p + zc);
     };
@@ -219,7 +224,8 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
             constexpr int g = decltype(gc)::value;
             constexpr int NQ = C::tab.nq[g], XHI = C::tab.xlo[g] + C::tab.nq[g] - 1;
             constexpr bool slabg = C::tab.slab[g];
-            if constexpr (NQ > 0) nxt[g] = ld_own(gc, x + XHI);
+            if constexpr (NQ > 0)
+                static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; nxt[j][g] = ld_own(gc, j, x + XHI); });
             if constexpr (slabg) {
                 constexpr int NHT = C::tab.nht[g], HO = C::tab.hoff[g];
                 const T* p = (const T*)a.ptr[g] + (idx_t)xclamp(x) * a.gsx[g];
@@ -237,7 +243,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
         constexpr int NQ = C::tab.nq[g], QO = C::tab.qoff[g], XLO = C::tab.xlo[g];
         static_for<(NQ > 0 ? NQ - 1 : 0)>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            q[QO + i] = ld_own(gc, xs + XLO + i);
+            static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; q[j][QO + i] = ld_own(gc, j, xs + XLO + i); });
         });
     });
     prefetch(xs);
@@ -248,11 +254,15 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
             constexpr int g = decltype(gc)::value;
             constexpr int NQ = C::tab.nq[g], QO = C::tab.qoff[g], XLO = C::tab.xlo[g];
             constexpr bool slabg = C::tab.slab[g];
-            if constexpr (NQ > 0) q[QO + NQ - 1] = nxt[g];
+            if constexpr (NQ > 0)
+                static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; q[j][QO + NQ - 1] = nxt[j][g]; });
             if constexpr (slabg) {
                 constexpr int YL = C::tab.yl[g], ZLV = C::tab.zlv[g], LP = C::tab.lp[g], SO = C::tab.soff[g];
                 constexpr int NHT = C::tab.nht[g], HO = C::tab.hoff[g];
-                stv<V>(sb + SO + (YL + ly) * LP + (ZLV + lz) * VZ, q[QO - XLO]);
+                static_for<RY>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    stv<V>(sb + SO + (YL + ly * RY + j) * LP + (ZLV + lz) * VZ, q[j][QO - XLO]);
+                });
                 static_for<NHT>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     if (hlds[HO + k] >= 0) stv<V>(sb + hlds[HO + k], hreg[HO + k]);
@@ -262,28 +272,32 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
         if (x + 1 < xe) prefetch(x + 1);
         __syncthreads();
 
-        V out[MAX_GROUPS];
-        MarchAcc<C, P> acc{a, q, sb, ly, lz, x, myy, myz, out};
-        P::eval(acc);
-        if (myy < a.y1 && myz < a.z1 && myz + VZ > a.z0) {
-            static_for<P::n_writes>([&](auto wc) {
-                constexpr int g = P::writes[decltype(wc)::value];
-                T* op = (T*)a.ptr[g] + (idx_t)x * a.gsx[g] + (idx_t)myy * a.gsy[g] + myz;
-                if (myz >= a.z0 && myz + VZ <= a.z1) stv<V>(op, out[g]);
-                else
-                    static_for<VZ>([&](auto ec) {
-                        constexpr int e = decltype(ec)::value;
-                        if (myz + e >= a.z0 && myz + e < a.z1) op[e] = out[g][e];
-                    });
-            });
-        }
+        static_for<RY>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int myy = myy0 + j;
+            V out[MAX_GROUPS];
+            MarchAcc<C, P, PIN> acc{a, q[j], sb, ly * RY + j, lz, x, myy, myz, out};
+            P::eval(acc);
+            if (myy < a.y1 && myz < a.z1 && myz + VZ > a.z0) {
+                static_for<P::n_writes>([&](auto wc) {
+                    constexpr int g = P::writes[decltype(wc)::value];
+                    T* op = (T*)a.ptr[g] + (idx_t)x * a.gsx[g] + (idx_t)myy * a.gsy[g] + myz;
+                    if (myz >= a.z0 && myz + VZ <= a.z1) stv<V>(op, out[g]);
+                    else
+                        static_for<VZ>([&](auto ec) {
+                            constexpr int e = decltype(ec)::value;
+                            if (myz + e >= a.z0 && myz + e < a.z1) op[e] = out[g][e];
+                        });
+                });
+            }
+        });
         // rotate the queues
         static_for<NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             constexpr int NQ = C::tab.nq[g], QO = C::tab.qoff[g];
             static_for<(NQ > 0 ? NQ - 1 : 0)>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                q[QO + i] = q[QO + i + 1];
+                static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; q[j][QO + i] = q[j][QO + i + 1]; });
             });
         });
     }

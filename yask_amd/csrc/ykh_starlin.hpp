@@ -129,6 +129,7 @@ struct LinAcc {
     }
     template <int G>
     __device__ __forceinline__ void wr(V v) { out[G] = v; }
+    __device__ __forceinline__ void pin(V&) const {}
 };
 
 template <class V, typename T> __device__ __forceinline__ V ldv(const T* p) { return *reinterpret_cast<const V*>(p); }

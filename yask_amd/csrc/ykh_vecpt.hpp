@@ -46,6 +46,7 @@ struct VecPtAcc {
                 if (z0 + e >= a.z0 && z0 + e < a.z1) p[e] = v[e];
             });
     }
+    __device__ __forceinline__ void pin(V&) const {}
     template <int D>
     __device__ __forceinline__ V idx() const {
         if constexpr (D == 2) { V r; static_for<VZ>([&](auto ec) { constexpr int e = decltype(ec)::value; r[e] = T(z0 + e + a.ofs_z); }); return r; }
