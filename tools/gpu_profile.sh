@@ -26,7 +26,7 @@ for f in glob.glob("$OUT/pmc_*/**/*counter_collection.csv", recursive=True):
             out.setdefault(k, {})[c] = {"avg": sum(v) / len(v), "n": len(v)}
 json.dump(out, open("$OUT/pmc_summary.json", "w"), indent=1)
 for k, d in out.items():
-    if "star25d" in k or "naive" in k:
+    if any(t in k for t in ("star25d", "starlin", "march", "vecpt", "naive")):
         print(k, {c: round(x["avg"], 1) for c, x in d.items()})
 for f in glob.glob("$OUT/stats/**/*kernel_stats.csv", recursive=True):
     print(open(f).read()[:1500])

@@ -23,19 +23,20 @@ def main():
     ap.add_argument("--steps", type=int, default=0, help="also time N whole steps with the default variants")
     args = ap.parse_args()
     from yask_amd import yk_factory
-    from oracle import oracle as O
     size = args.size if len(args.size) == 3 else [args.size[0]] * 3
     fac = yk_factory(args.stencil)
     env = fac.new_env()
+
+    def init(s):
+        # var k = 1 + k/4 + 0.1*hash(logical index): O(1) data, the same in every solution (as yask_amd/harness.py)
+        for k, v in enumerate(s.get_vars()):
+            v.set_elements_hash(1.0 + 0.25 * k, 0.1, hash_id=k)
 
     def make():
         s = fac.new_solution(env)
         s.set_overall_domain_size_vec(size)
         s.prepare_solution()
-        for v in s.get_vars():
-            key = args.stencil if args.stencil in O.DEFAULT_INIT else args.stencil.split("_r")[0]
-            off, sc = O.DEFAULT_INIT.get(key, {}).get(v.get_name(), (1.5, 0.5))
-            v.set_elements_hash(off, sc, hash_id=O.VAR_IDS.get(key, {}).get(v.get_name(), 0))
+        init(s)
         return s
 
     soln = make()
@@ -44,9 +45,7 @@ def main():
         ref = make()
         ref.apply_command_line_options("-force_scalar")
         ref.prepare_solution()
-        for v in ref.get_vars():
-            off, sc = O.DEFAULT_INIT[args.stencil][v.get_name()]
-            v.set_elements_hash(off, sc, hash_id=O.VAR_IDS[args.stencil][v.get_name()])
+        init(ref)
         ref.run_solution(0, 1)
     pts = float(size[0]) * size[1] * size[2]
     names = soln.get_kernel_variant_names(args.part)
@@ -69,9 +68,7 @@ def main():
             chk = make()
             chk.apply_command_line_options(f"-hip_variant {name}")
             chk.prepare_solution()
-            for v in chk.get_vars():
-                off, sc = O.DEFAULT_INIT[args.stencil][v.get_name()]
-                v.set_elements_hash(off, sc, hash_id=O.VAR_IDS[args.stencil][v.get_name()])
+            init(chk)
             chk.run_solution(0, 1)
             bad = chk.compare_data(ref, 1e-4)
             print("check", name, "mismatches vs naive:", bad, flush=True)
