@@ -1,0 +1,97 @@
+"""Python API parity: the flow of the reference's Python kernel-API test
+(src/kernel/tests/yask_kernel_api_test.py:30-340, written against the SWIG module `yask_kernel`) restated
+against this repo's `yask_kernel` module (yask_kernel.py -> yask_amd/kernel.py, ctypes over the C ABI), with
+the reference's SWIG calling conventions: factory without arguments, `ndarray.data` buffers first,
+deprecated alloc-index aliases, raw storage pointers.  (The reference script itself was run unchanged
+against this module on the MI355X during development -- INTEGRATION.md section 2b -- but reference sources
+are not stored here, so the test restates it.)"""
+import ctypes as ct
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _slice_of(soln, var, t):
+    first, last, shape, point = [], [], [], ()
+    for d in var.get_dim_names():
+        if d == soln.get_step_dim_name():
+            a = b = t
+        elif d in soln.get_domain_dim_names():
+            a, b = var.get_first_rank_alloc_index(d), var.get_last_rank_alloc_index(d)
+        else:
+            a, b = var.get_first_misc_index(d), var.get_last_misc_index(d)
+        first.append(a); last.append(b); shape.append(b - a + 1); point += (0,)
+    return first, last, shape, point
+
+
+def test_python_api_flow_like_the_reference(gpu, monkeypatch):
+    monkeypatch.setenv("YASK_STENCIL", "test_3d")          # the stencil src/kernel/Makefile:981-985 uses
+    import yask_kernel as yk
+    kfac = yk.yk_factory()
+    yk.yask_output_factory()
+    env = kfac.new_env()
+    env.set_trace_enabled(False)
+    soln = kfac.new_solution(env)
+    assert soln.get_name() == "test_3d"
+    dtype = np.float32 if soln.get_element_bytes() == 4 else np.float64
+    dims = soln.get_domain_dim_names()
+    for d in dims:
+        soln.set_overall_domain_size(d, 128)
+        soln.set_min_pad_size(d, 1)
+        soln.set_block_size(d, 64 if d == "z" else 32)
+    fvar = soln.new_fixed_size_var("fvar", dims, (5,) * len(dims))
+    fvar.set_numa_preferred(yk.cvar.yask_numa_local)
+    fvar.alloc_storage()
+    soln.prepare_solution()
+    assert soln.get_step_dim_name() == "t" and dims == ["x", "y", "z"]
+
+    for var in soln.get_vars():
+        var.set_all_elements_same(-9.0)
+        if var.is_fixed_size():
+            continue
+        # init step 0 through a NumPy buffer handed over as `ndarray.data` (SWIG pybuffer order: buffer first)
+        first, last, shape, point = _slice_of(soln, var, 0)
+        nd = np.zeros(shape, dtype, "C")
+        nd[point] = 21.0
+        nset = var.set_elements_in_slice(nd.data, first, last)
+        assert nset == nd.size
+        assert var.get_element(first) == 21.0
+        assert var.get_element(last) == 0.0
+        nd2 = np.full(shape, 5.0, dtype)
+        assert var.get_elements_in_slice(nd2.data, first, last) == nd2.size
+        assert nd2[point] == 21.0 and nd2.sum() == 21.0
+        assert var.set_element(22.0, last) == 1 and var.get_element(last) == 22.0
+        assert var.add_to_element(2.0, last) == 1 and var.get_element(last) == 24.0
+        # raw storage: a host pointer to num_storage_elements values (yk_var_api.hpp:1437)
+        ptype = ct.POINTER(ct.c_float if dtype == np.float32 else ct.c_double)
+        fp = ct.cast(int(var.get_raw_storage_buffer()), ptype)
+        n = var.get_num_storage_elements()
+        assert n >= nd.size and np.isfinite(fp[0]) and np.isfinite(fp[n - 1])
+        # one point and a small cube, non-strict indices
+        one = [0 if d == "t" else 100 for d in var.get_dim_names()]
+        assert var.set_element(15.0, one, False) == 1
+        mid = [soln.get_overall_domain_size(d) // 2 for d in dims]
+        f = [0] + [m - 20 for m in mid]
+        l = [0] + [m + 20 for m in mid]
+        assert var.set_elements_in_slice_same(0.5, f, l, False) == 41 ** 3
+        assert var.get_first_local_index_vec()[1:] == [var.get_first_rank_alloc_index(d) for d in dims]
+
+    env.global_barrier()
+    soln.run_solution(0)
+    for var in soln.get_vars():
+        if not var.is_fixed_size():
+            assert var.get_last_valid_step_index() == 1
+    soln.run_solution(1, 4)
+    for var in soln.get_vars():
+        if not var.is_fixed_size():
+            first, last, shape, _ = _slice_of(soln, var, 5)
+            out = np.zeros(shape, dtype)
+            assert var.get_elements_in_slice(out.data, first, last) == out.size
+            assert np.isfinite(out).all() and np.abs(out).max() > 0
+    soln.end_solution()
+    st = soln.get_stats()
+    assert st.get_num_steps_done() == 5
+    env.finalize()

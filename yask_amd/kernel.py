@@ -104,6 +104,11 @@ class yk_var:
         return sum(1 for d in self.get_dim_names() if d in dd)
     def is_dim_used(self, dim): return bool(self._lib.call("yk_var_is_dim_used", self._h, _b(dim)))
     def is_fixed_size(self): return bool(self._lib.call("yk_var_is_fixed_size", self._h))
+    # deprecated aliases kept by the reference (yk_var_api.hpp:1472-1487)
+    def get_first_rank_alloc_index(self, dim): return self.get_first_local_index(dim)
+    def get_last_rank_alloc_index(self, dim): return self.get_last_local_index(dim)
+    def set_numa_preferred(self, numa_node): return False          # device memory: no NUMA policy
+    def get_numa_preferred(self): return -9                         # yask_numa_none
     def get_first_valid_step_index(self): return self._lib.call("yk_var_get_first_valid_step_index", self._h)
     def get_last_valid_step_index(self): return self._lib.call("yk_var_get_last_valid_step_index", self._h)
 
@@ -130,21 +135,43 @@ class yk_var:
     def _np_dtype(self):
         return np.float32 if self._soln.get_element_bytes() == 4 else np.float64
 
-    def get_elements_in_slice(self, first_indices, last_indices, buffer=None):
-        """Returns a numpy array shaped (last-first+1) per dim (row-major, var dim order).
-        With `buffer` (a writable float32/float64 array) fills it like the C++ overloads."""
+    @staticmethod
+    def _as_array(buf, dtype, writable):
+        """numpy view of a caller buffer (ndarray, memoryview from `ndarray.data`, bytearray ...), as the SWIG
+        `pybuffer` typemaps of src/kernel/swig/yask_kernel_api.i accept them."""
+        if isinstance(buf, np.ndarray):
+            return buf
+        a = np.frombuffer(buf, dtype=dtype)
+        if writable and not a.flags.writeable:
+            raise RuntimeError("YASK error: buffer is read-only")
+        return a
+
+    def get_elements_in_slice(self, *args, buffer=None):
+        """get_elements_in_slice(first_indices, last_indices[, buffer]) -> numpy array shaped (last-first+1) per dim
+        (row-major, var dim order); or, SWIG order, get_elements_in_slice(buffer, first_indices, last_indices) ->
+        number of elements read into the caller's float32/float64 buffer (yk_var_api.hpp:699-744)."""
+        swig_order = len(args) == 3 and not isinstance(args[0], (list, tuple)) and not (
+            isinstance(args[0], np.ndarray) and args[0].dtype.kind in "iu")
+        if swig_order:
+            buffer, first_indices, last_indices = args
+        else:
+            first_indices, last_indices = args[0], args[1]
+            if len(args) > 2:
+                buffer = args[2]
         f, l = list(first_indices), list(last_indices)
         shape = [int(b) - int(a) + 1 for a, b in zip(f, l)]
         if buffer is None:
             buffer = np.empty(shape, dtype=self._np_dtype())
-        if buffer.dtype not in (np.float32, np.float64) or not buffer.flags.c_contiguous:
+        arr = self._as_array(buffer, self._np_dtype(), True)
+        if arr.dtype not in (np.float32, np.float64) or not arr.flags.c_contiguous:
             raise RuntimeError("YASK error: get_elements_in_slice needs a C-contiguous float32/float64 buffer")
-        fn = "yk_var_get_elements_in_slice_f32" if buffer.dtype == np.float32 else "yk_var_get_elements_in_slice_f64"
-        self._lib.call(fn, self._h, buffer.ctypes.data_as(C.c_void_p), buffer.size, self._idx(f), self._idx(l))
-        return buffer
+        fn = "yk_var_get_elements_in_slice_f32" if arr.dtype == np.float32 else "yk_var_get_elements_in_slice_f64"
+        n = self._lib.call(fn, self._h, arr.ctypes.data_as(C.c_void_p), arr.size, self._idx(f), self._idx(l))
+        return n if swig_order else arr
 
     def set_elements_in_slice(self, buffer, first_indices, last_indices):
-        a = np.ascontiguousarray(buffer)
+        a = self._as_array(buffer, self._np_dtype(), False)
+        a = np.ascontiguousarray(a)
         if a.dtype not in (np.float32, np.float64):
             a = a.astype(self._np_dtype())
         fn = "yk_var_set_elements_in_slice_f32" if a.dtype == np.float32 else "yk_var_set_elements_in_slice_f64"
