@@ -45,6 +45,14 @@ GENERIC_CASES = [
     ("test_partial_3d_16x18x20_s2", "test_partial_3d", (16, 18, 20), 2),
     ("test_stream_3d_16x18x20_s3", "test_stream_3d", (16, 18, 20), 3),
     ("test_func_1d_80_s2", "test_func_1d", (80,), 2),
+    # solutions of the reference's stencil library beyond the three hot-path ones
+    ("awp_abc_24x20x28_s2", "awp_abc", (24, 20, 28), 2),          # AwpStencil.cpp: 43 vars, 7 parts, boundary conditions
+    ("tti_20x18x24_s2", "tti", (20, 18, 24), 2),                  # TTIStencil.cpp
+    ("iso3dfd_sponge_24x20x28_s3", "iso3dfd_sponge", (24, 20, 28), 3),   # Iso3dfdStencil.cpp with sponge vars
+    ("wave2d_48x40_s3", "wave2d", (48, 40), 3),                   # Wave2dStencil.cpp: 15 conditional parts
+    ("ssg2_20x18x24_s2", "ssg2", (20, 18, 24), 2),                # SSGElastic2Stencil.cpp
+    ("fsg2_16x14x20_s2", "fsg2", (16, 14, 20), 2),                # FSGElastic2Stencil.cpp: 81 access groups in one part
+    ("cube_20x18x24_s3", "cube", (20, 18, 24), 3),                # SimpleStencils.cpp: dense 3-D cube
 ]
 GENERIC_INIT = (1.5, 0.5)
 

@@ -56,7 +56,7 @@ template <> struct vtraits<double> {
 };
 
 // ------------------------------------------------------------------ kernel arguments
-constexpr int MAX_GROUPS = 24;
+constexpr int MAX_GROUPS = 96;     // PartArgs stays under the 4 KiB kernel-argument limit (fsg_abc needs 93)
 
 // All quantities are in *rank-local* element coordinates: index 0 is the first domain point of
 // this rank in each dim; halos/pads have negative indices or indices >= the local domain size.
