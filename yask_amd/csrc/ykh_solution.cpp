@@ -392,6 +392,38 @@ void Solution::prepare() {
                 YKH_THROW("unknown -hip_variant '" + variant_override + "'; available:" + names);
             }
         }
+        if (variant_override.empty() && !force_scalar && ndd == 3 && pi.variants[v].star && pi.variants[v].rx == 0) {
+            // Small grids: the default (largest) tile can leave most CUs without a workgroup.  Among the
+            // compiled tile shapes of the same kernel family pick the one that fills the most CUs (ties: the
+            // larger tile); x-chunks shorter than 32 planes are not worth their halo planes.
+            auto blocks_of = [&](const KernelVariant& kv) -> idx_t {
+                return ceil_div(local_size[2], (idx_t)kv.tz) * ceil_div(local_size[1], (idx_t)kv.ty) *
+                       std::max<idx_t>(1, local_size[0] / 32);
+            };
+            const idx_t cus = std::max(1, env->num_cus);
+            if (blocks_of(pi.variants[v]) < cus) {
+                const std::string dn = pi.variants[v].name;
+                const std::string family = dn.substr(0, dn.find("_z"));
+                // score = share of the CUs that get a workgroup x share of a tile's lanes that do useful work
+                auto score_of = [&](const KernelVariant& kv) -> double {
+                    double fill = (double)std::min(blocks_of(kv), cus) / (double)cus;
+                    double useful = (double)(local_size[2] * local_size[1]) /
+                                    (double)(ceil_div(local_size[2], (idx_t)kv.tz) * kv.tz * ceil_div(local_size[1], (idx_t)kv.ty) * kv.ty);
+                    return fill * useful;
+                };
+                double best = score_of(pi.variants[v]);
+                idx_t best_area = (idx_t)pi.variants[v].tz * pi.variants[v].ty;
+                for (size_t k = 0; k < pi.variants.size(); k++) {
+                    const KernelVariant& kv = pi.variants[k];
+                    const std::string kn = kv.name;
+                    if (!kv.star || kv.rx > 0 || kn.compare(0, 3, "abl") == 0 || kn.compare(0, family.size(), family) != 0) continue;
+                    if (kn.find("_pd2") != std::string::npos || kn.find("_cd2") != std::string::npos || kn.find("_hl") != std::string::npos) continue;
+                    double sc = score_of(kv);
+                    idx_t area = (idx_t)kv.tz * kv.ty;
+                    if (sc > best * 1.001 || (sc > best * 0.999 && area > best_area)) { best = sc; best_area = area; v = (int)k; }
+                }
+            }
+        }
         part_variant[p] = v;
         part_xchunk[p] = xchunk_override;
     }
