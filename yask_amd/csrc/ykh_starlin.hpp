@@ -110,6 +110,16 @@ struct StarLinCfg {
     // y neighbours with a non-zero coefficient, in offset order
     static constexpr int count_y() { int n = 0; for (int dy = -YL; dy <= YH; dy++) if (dy != 0 && lin_coef<P>(0, dy, 0) != 0.0) n++; return n; }
     static constexpr int NY = count_y();
+    // rows of the y window shared by the RY rows of a thread: offsets (relative to the thread's first row)
+    // -YL .. RY-1+YH without the thread's own rows, kept if some row has a non-zero coefficient for it
+    static constexpr bool yw_used(int w) {
+        if (w >= 0 && w < RY) return false;
+        for (int j = 0; j < RY; j++) { int dy = w - j; if (dy >= -YL && dy <= YH && dy != 0 && lin_coef<P>(0, dy, 0) != 0.0) return true; }
+        return false;
+    }
+    static constexpr int count_yw() { int n = 0; for (int w = -YL; w <= RY - 1 + YH; w++) if (yw_used(w)) n++; return n; }
+    static constexpr int NYW = count_yw();
+    static constexpr int yw_off(int i) { int n = 0; for (int w = -YL; w <= RY - 1 + YH; w++) if (yw_used(w)) { if (n == i) return w; n++; } return 0; }
     static constexpr int y_off(int i) { int n = 0; for (int dy = -YL; dy <= YH; dy++) if (dy != 0 && lin_coef<P>(0, dy, 0) != 0.0) { if (n == i) return dy; n++; } return 0; }
 };
 
@@ -132,6 +142,8 @@ struct LinAcc {
     __device__ __forceinline__ void pin(V&) const {}
 };
 
+// Keep `v` (and, through the memory clobber, later memory reads) at this point of the program order.
+template <class V> __device__ __forceinline__ void pin_reg(V& v) { asm volatile("" : "+v"(v) : : "memory"); }
 template <class V, typename T> __device__ __forceinline__ V ldv(const T* p) { return *reinterpret_cast<const V*>(p); }
 // uniform base + 32-bit unsigned byte offset (selects the saddr form of global_load/store)
 template <class V, typename T> __device__ __forceinline__ V ldv_b(const T* base, unsigned byte_off) {
@@ -316,41 +328,52 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
         __syncthreads();
 
         const T* colp = sb + (ZLV + lz) * VZ;
+        const T* row0 = colp + (YL + ly * RY) * LP;      // the thread's first row in the slab
+        // ---- new partial sums for output plane xin, all RY rows of the thread together.
+        // Centre and past x come from registers ...
+        V c[RY], sum[RY];
         static_for<RY>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            const V c = pq[qn][j];
-            const T* rowc = colp + (YL + ly * RY + j) * LP;     // own element in the slab
-            // ---- new partial sum for output plane xin: centre and past x from registers ...
             constexpr T c000 = T(lin_coef<P>(0, 0, 0));
-            V s = c * c000;
+            c[j] = pq[qn][j];
+            sum[j] = c[j] * c000;
             static_for<XL>([&](auto kc) {
                 constexpr int k = decltype(kc)::value + 1;
                 constexpr T ck = T(lin_coef<P>(-k, 0, 0));
                 constexpr int qi = rot<NP>(PH, NP - 1 - k);
-                s += pq[qi][j] * ck;
+                sum[j] += pq[qi][j] * ck;
             });
-            // ... y neighbours from the slab and z neighbours from a window of the own row, in batches
-            // of CH reads, double-buffered: while batch b is summed, batch b+1 is in flight.  The
-            // empty asm pins the partial sum (and, through its memory clobber, the later reads) in
-            // program order; unconstrained, hipcc issues all NY+NW reads first and needs VZ*(NY+NW)
-            // more VGPRs, which costs a wave per SIMD.
-            constexpr int NZW = (C::ZL + C::ZH > 0) ? C::NW - 1 : 0;       // window reads (own vector comes from c)
-            constexpr int NRD = NY + NZW;                                  // LDS reads per row
-            constexpr int NB = (NRD + CH - 1) / CH;
+        });
+        // ... the thread's own rows are y-neighbours of each other (registers) ...
+        static_for<RY>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            static_for<RY>([&](auto j2c) {
+                constexpr int dy = decltype(j2c)::value - j;
+                if constexpr (dy != 0 && dy >= -YL && dy <= C::YH) {
+                    if constexpr (lin_coef<P>(0, dy, 0) != 0.0) {
+                        constexpr T ck = T(lin_coef<P>(0, dy, 0));
+                        sum[j] += c[decltype(j2c)::value] * ck;
+                    }
+                }
+            });
+        });
+        // ... the other y-neighbours come from ONE window of slab rows shared by the RY rows (YL+YH reads
+        // instead of RY*(YL+YH)); every value read feeds the sums of all rows it is a neighbour of, which
+        // also gives RY independent FMA chains.  Reads go in batches of CH, double-buffered: while batch b is
+        // summed, batch b+1 is in flight.  The empty asm pins the partial sums (and, through its memory
+        // clobber, the later reads) in program order; unconstrained, hipcc issues all reads first and needs
+        // VZ*(NYW+NW) more VGPRs.
+        {
+            constexpr int NYW = C::NYW;
+            constexpr int NB = (NYW + CH - 1) / CH;
             V t[NB > 0 ? NB : 1][CH];
-            V zw[C::NW];
-            zw[ZLV] = c;
             auto issue = [&](auto bc) {
                 constexpr int b = decltype(bc)::value;
                 static_for<CH>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, r = b * CH + i;
-                    if constexpr (r < NY) {
-                        constexpr int dy = C::y_off(r);
-                        t[b][i] = ldv<V>(rowc + dy * LP);
-                    }
-                    else if constexpr (r < NRD) {
-                        constexpr int w = (r - NY) < ZLV ? (r - NY) : (r - NY) + 1;
-                        zw[w] = ldv<V>(rowc + (w - ZLV) * VZ);
+                    if constexpr (r < NYW) {
+                        constexpr int w = C::yw_off(r);
+                        t[b][i] = ldv<V>(row0 + w * LP);
                     }
                 });
             };
@@ -360,31 +383,56 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
                 if constexpr (b + 1 < NB) issue(std::integral_constant<int, b + 1>{});
                 static_for<CH>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, r = b * CH + i;
-                    if constexpr (r < NY) {
-                        constexpr int dy = C::y_off(r);
-                        constexpr T ck = T(lin_coef<P>(0, dy, 0));
-                        s += t[b][i] * ck;
+                    if constexpr (r < NYW) {
+                        constexpr int w = C::yw_off(r);
+                        static_for<RY>([&](auto jc) {
+                            constexpr int j = decltype(jc)::value;
+                            constexpr int dy = w - j;
+                            if constexpr (dy >= -YL && dy <= C::YH) {
+                                if constexpr (lin_coef<P>(0, dy, 0) != 0.0) {
+                                    constexpr T ck = T(lin_coef<P>(0, dy, 0));
+                                    sum[j] += t[b][i] * ck;
+                                }
+                            }
+                        });
                     }
                 });
-                asm volatile("" : "+v"(s) : : "memory");
+                static_for<RY>([&](auto jc) { pin_reg(sum[decltype(jc)::value]); });
             });
+        }
+        static_for<RY>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            // ... z neighbours from a window of the row itself
+            constexpr int NZW = (C::ZL + C::ZH > 0) ? C::NW - 1 : 0;       // window reads (own vector comes from c)
             if constexpr (NZW > 0) {
+                const T* rowc = row0 + j * LP;
+                V zw[C::NW];
+                zw[ZLV] = c[j];
+                static_for<C::NW>([&](auto wc) {
+                    constexpr int w = decltype(wc)::value;
+                    if constexpr (w != ZLV) zw[w] = ldv<V>(rowc + (w - ZLV) * VZ);
+                });
                 static_for<C::ZL + C::ZH + 1>([&](auto dc) {
                     constexpr int dz = decltype(dc)::value - C::ZL;
                     if constexpr (dz != 0 && lin_coef<P>(0, 0, dz) != 0.0) {
                         constexpr int e = ZLV * VZ + dz;
                         constexpr T ck = T(lin_coef<P>(0, 0, dz));
-                        s += zshiftn<T, VZ, e % VZ>(zw[e / VZ], zw[(e / VZ + 1) < C::NW ? (e / VZ + 1) : e / VZ]) * ck;
+                        sum[j] += zshiftn<T, VZ, e % VZ>(zw[e / VZ], zw[(e / VZ + 1) < C::NW ? (e / VZ + 1) : e / VZ]) * ck;
                     }
                 });
+                pin_reg(sum[j]);
             }
+        });
+        static_for<RY>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const V s = sum[j];
             acc[an][j] = s;
             // ---- this plane's contribution to the outputs still waiting for their future
             static_for<XH>([&](auto kc) {
                 constexpr int k = decltype(kc)::value + 1;
                 constexpr T ck = T(lin_coef<P>(k, 0, 0));
                 constexpr int ai = rot<NA>(PH, NA - 1 - k);
-                acc[ai][j] += c * ck;
+                acc[ai][j] += c[j] * ck;
             });
             // ---- output plane xo = xin - XH is complete
             V cj[MAX_GROUPS], out[MAX_GROUPS];
