@@ -124,7 +124,7 @@ def main():
     elapsed = time.perf_counter() - t0
     t += args.steps
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
     pts_per_gpu = float(n) ** 3

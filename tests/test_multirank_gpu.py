@@ -131,3 +131,25 @@ def test_axis3_two_ranks_y_split(gpu):
     two = _two_ranks("3axis", g, steps, "", (1, 2, 1))
     ref = O.run_axis3(g, steps)[("A", steps)]
     assert O.rel_linf(two["A"], ref) <= 1e-12
+
+
+def test_bench_two_ranks_on_one_gpu(gpu):
+    """bench.py's N>1 flow (rank env from torch.distributed.run, x-slab decomposition, barrier-bracketed timing,
+    max over ranks, one JSON line from rank 0), with gloo + the host-staged transport so that two ranks can share
+    the single GPU of the test box."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, YASK_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--size", "128", "--transport", "torch"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["config"]["decomposition"] == "x-slabs 2x1x1" and "global 256x128x128" in j["config"]["workload"]

@@ -35,7 +35,8 @@ def init_process_group(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # YASK_DIST_BACKEND=gloo: several ranks on ONE GPU (tests; RCCL needs one device per rank)
+            backend = os.environ.get("YASK_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
