@@ -18,7 +18,7 @@ const SolnImpl& ykh_solution_impl() {
         p.variants.push_back(naive_variant<part_1>());
         s3axis_variants_k1(p);
         s3axis_variants_k2(p);
-        p.set_default("starlin_v2_z64_y32_r2_m_nt_w2_c4");
+        p.set_default("starlin_v2_z64_y32_r2_u_nt_w2_c4");
         s.parts.push_back(p);
         return s;
     }();
