@@ -25,7 +25,7 @@ const SolnImpl& ykh_solution_impl() {
         iso3dfd_variants_k3(p);
         iso3dfd_variants_k4(p);
         iso3dfd_variants_k5(p);
-        p.set_default("starlin_v4_z128_y32_r2_m_nt_w2_c4");
+        p.set_default("starlin_v4_z128_y32_r2_m_nt_pd2_w2_c2");
         s.parts.push_back(p);
         return s;
     }();

@@ -8,8 +8,13 @@ using namespace ykh_gen_iso3dfd;
 void iso3dfd_variants_k4(PartImpl& p) {
     p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 3, 2, 4, 0>());   // halos after row 0
     p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 5, 2, 4, 0>());   // halos at the end
-    p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 1, ROT_MOVE, 25, 2, 4, 0>());   // 128x16 tile, everything 2 ahead
-    p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 1, ROT_MOVE, 9, 2, 4, 0>());    // 128x16 tile, depth 2
+    p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 1, 2, 2, 0>());    // LDS batches of 2
+    p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 17, 2, 2, 0>());   // + operands two planes ahead
+    p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 9, 2, 2, 0>());    // + star planes two planes ahead
+    p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 29, 2, 2, 0>());   // + both, halos at the end
+    p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 13, 2, 2, 0>());   // planes two ahead, halos at the end
+    p.variants.push_back(starlin_variant<part_1, 4, 64, 8, 2, ROT_MOVE, 9, 2, 2, 0>());     // 256x16 tile, planes two ahead
+    p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 1, ROT_UNROLL, 1, 2, 4, 0>());  // 128x16, queue rotation by renaming
     // 256-thread workgroups, two per CU: independent barriers, one computes while the other waits on memory
     p.variants.push_back(starlin_variant<part_1, 4, 32, 8, 2, ROT_MOVE, 1, 2, 4, 0>());    // tile 128x16
     p.variants.push_back(starlin_variant<part_1, 4, 64, 8, 2, ROT_MOVE, 1, 2, 4, 0>());

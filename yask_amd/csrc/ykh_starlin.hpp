@@ -180,9 +180,9 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
     constexpr int SG = C::SG, NG = P::n_groups;
     constexpr bool NT_STREAMS = (NTH & 1) != 0;
     constexpr int HALO_LATE = (NTH >> 1) & 3;
-    constexpr int PD = ((NTH >> 3) & 1) ? 2 : 1;      // prefetch depth in planes
+    constexpr int PD = ((NTH >> 5) & 1) ? 3 : (((NTH >> 3) & 1) ? 2 : 1);      // prefetch depth in planes (bit 5: three)
     constexpr int CD = ((NTH >> 4) & 1) ? 2 : 1;      // prefetch depth of the centre-only operands
-    constexpr int TRIP = (PD > CD) ? PD : CD;         // planes per loop trip (register sets alternate)
+    constexpr int TRIP = PD * CD / ce_gcd(PD, CD);    // planes per loop trip (the register sets rotate)
     static_assert(CD == 1 || XH > 0, "operand prefetch depth 2 needs a future x range");
     static_assert(!C::R.mixed, "linear form has a mixed-offset term");
     static_assert(NG <= MAX_GROUPS, "too many access groups");
@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
             static_for<TRIP>([&](auto sc) { plane(x + decltype(sc)::value, I0{}, sc); rotate(); });
     } else {
         // UNR planes per trip (queue rotation by renaming); the last trip may run past xlast-1.
-        static_assert(TRIP == 1 || C::UNR % 2 == 0, "prefetch depth 2 needs an even unroll count");
+        static_assert(C::UNR % TRIP == 0, "the unroll count must be a multiple of the prefetch trip");
         for (int x = xs; x < xlast; x += C::UNR)
             static_for<C::UNR>([&](auto phc) { plane(x + decltype(phc)::value, phc, phc); });
     }
