@@ -23,7 +23,7 @@ const SolnImpl& ykh_solution_impl() {
             p.variants.push_back(vecpt_variant<part_1, 4, 64, 4, 4>());
             p.variants.push_back(vecpt_variant<part_1, 2, 64, 4, 2>());
             ssg_variants_k1(p);
-            p.set_default("march_v2_z64_y16_w2");
+            p.set_default("march_v2_z128_y8_pd2_w2");
             s.parts.push_back(p);
         }
         {
@@ -36,7 +36,7 @@ const SolnImpl& ykh_solution_impl() {
             p.variants.push_back(vecpt_variant<part_2, 4, 64, 4, 4>());
             p.variants.push_back(vecpt_variant<part_2, 2, 64, 4, 2>());
             ssg_variants_k2(p);
-            p.set_default("march_v2_z64_y16_w2");
+            p.set_default("march_v2_z128_y8_pd2_w2");
             s.parts.push_back(p);
         }
         return s;

@@ -9,5 +9,7 @@ void ssg_variants_k1(PartImpl& p) {
     p.variants.push_back(march_variant<part_1, 2, 32, 16, 2>());
     p.variants.push_back(march_variant<part_1, 2, 64, 4, 2>());
     p.variants.push_back(march_variant<part_1, 2, 64, 8, 2, 1, true>());   // strict program order (pin() after every temporary)
+    p.variants.push_back(march_variant<part_1, 2, 32, 16, 2, 1, false, 2>());   // two planes ahead
+    p.variants.push_back(march_variant<part_1, 2, 64, 8, 2, 1, false, 2>());
 }
 }  // namespace ykh

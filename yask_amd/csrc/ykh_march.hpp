@@ -142,7 +142,8 @@ struct MarchAcc {
     __device__ __forceinline__ V step() const { return V(T(a.t)); }
 };
 
-template <class P, int VZ, int TZL, int TYL, int MINW, int RY = 1, bool PIN = false>
+// PD: planes prefetched ahead (1 or 2; 2 = two alternating register sets, twice the bytes in flight).
+template <class P, int VZ, int TZL, int TYL, int MINW, int RY = 1, bool PIN = false, int PD = 1>
 __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a) {
     typedef MarchCfg<P, VZ, TZL, TYL, RY> C;
     typedef typename C::T T;
@@ -209,8 +210,8 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
     });
 
     V q[RY][C::NQTOT > 0 ? C::NQTOT : 1];
-    V nxt[RY][NG];
-    V hreg[C::NHTOT > 0 ? C::NHTOT : 1];
+    V nxt[PD][RY][NG];
+    V hreg[PD][C::NHTOT > 0 ? C::NHTOT : 1];
 
     // load the own-point vector of group g, row j, at plane x (vars without z: broadcast)
     auto ld_own = [&](auto gc, int j, int x) -> V {
@@ -219,19 +220,20 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
         if (a.gsz[g] == 0) return V(p[0]);
         return ldv<V>(p + zc);
     };
-    auto prefetch = [&](int x) {      // everything needed to advance to centre plane x
+    auto prefetch = [&](int x, auto sc) {      // everything needed to advance to centre plane x, into register set S
+        constexpr int S = decltype(sc)::value;
         static_for<NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             constexpr int NQ = C::tab.nq[g], XHI = C::tab.xlo[g] + C::tab.nq[g] - 1;
             constexpr bool slabg = C::tab.slab[g];
             if constexpr (NQ > 0)
-                static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; nxt[j][g] = ld_own(gc, j, x + XHI); });
+                static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; nxt[S][j][g] = ld_own(gc, j, x + XHI); });
             if constexpr (slabg) {
                 constexpr int NHT = C::tab.nht[g], HO = C::tab.hoff[g];
                 const T* p = (const T*)a.ptr[g] + (idx_t)xclamp(x) * a.gsx[g];
                 static_for<NHT>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
-                    hreg[HO + k] = ldv<V>(p + hofs[HO + k]);
+                    hreg[S][HO + k] = ldv<V>(p + hofs[HO + k]);
                 });
             }
         });
@@ -246,16 +248,18 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
             static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; q[j][QO + i] = ld_own(gc, j, xs + XLO + i); });
         });
     });
-    prefetch(xs);
+    static_for<PD>([&](auto sc) { prefetch(xs + decltype(sc)::value, sc); });
 
-    for (int x = xs; x < xe; x++) {
+    // One centre plane; `sc` = register set holding its prefetched data (the plane's position in the trip).
+    auto plane = [&](int x, auto sc) {
+        constexpr int S = decltype(sc)::value;
         T* sb = slab + (x & 1) * C::SLAB_TOT;
         static_for<NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             constexpr int NQ = C::tab.nq[g], QO = C::tab.qoff[g], XLO = C::tab.xlo[g];
             constexpr bool slabg = C::tab.slab[g];
             if constexpr (NQ > 0)
-                static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; q[j][QO + NQ - 1] = nxt[j][g]; });
+                static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; q[j][QO + NQ - 1] = nxt[S][j][g]; });
             if constexpr (slabg) {
                 constexpr int YL = C::tab.yl[g], ZLV = C::tab.zlv[g], LP = C::tab.lp[g], SO = C::tab.soff[g];
                 constexpr int NHT = C::tab.nht[g], HO = C::tab.hoff[g];
@@ -265,11 +269,11 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
                 });
                 static_for<NHT>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
-                    if (hlds[HO + k] >= 0) stv<V>(sb + hlds[HO + k], hreg[HO + k]);
+                    if (hlds[HO + k] >= 0) stv<V>(sb + hlds[HO + k], hreg[S][HO + k]);
                 });
             }
         });
-        if (x + 1 < xe) prefetch(x + 1);
+        prefetch(x + PD, sc);            // loads are clamped into the allocation
         __syncthreads();
 
         static_for<RY>([&](auto jc) {
@@ -278,7 +282,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
             V out[MAX_GROUPS];
             MarchAcc<C, P, PIN> acc{a, q[j], sb, ly * RY + j, lz, x, myy, myz, out};
             P::eval(acc);
-            if (myy < a.y1 && myz < a.z1 && myz + VZ > a.z0) {
+            if (x < xe && myy < a.y1 && myz < a.z1 && myz + VZ > a.z0) {
                 static_for<P::n_writes>([&](auto wc) {
                     constexpr int g = P::writes[decltype(wc)::value];
                     T* op = (T*)a.ptr[g] + (idx_t)x * a.gsx[g] + (idx_t)myy * a.gsy[g] + myz;
@@ -300,7 +304,10 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
                 static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; q[j][QO + i] = q[j][QO + i + 1]; });
             });
         });
-    }
+    };
+    // PD planes per trip; a trip may run past xe-1 (stores are predicated, loads clamped)
+    for (int x = xs; x < xe; x += PD)
+        static_for<PD>([&](auto sc) { plane(x + decltype(sc)::value, sc); });
 }
 
 }  // namespace ykh
