@@ -165,6 +165,9 @@ int yk_solution_set_streams(yk_soln_h s, void* compute_stream, void* comm_stream
 const char* yk_solution_get_kernel_variant(yk_soln_h s, int part);
 int yk_solution_get_num_kernel_variants(yk_soln_h s, int part);
 const char* yk_solution_get_kernel_variant_name(yk_soln_h s, int part, int i);
+/* bytes of scratch per thread of variant i's kernel (> 0: the compiler spilled registers; such shapes are never
+ * chosen by default or by the auto-tuner) */
+yk_idx_t yk_solution_get_kernel_variant_scratch_bytes(yk_soln_h s, int part, int i);
 /* Launch part `part` of step t once with variant i (or the selected one if i < 0) on the compute
  * stream, bracketed by HIP events; returns the kernel duration in ms in *ms. Used by bench.py. */
 int yk_solution_time_part(yk_soln_h s, int part, int variant, yk_idx_t xchunk, yk_idx_t t, int reps, float* ms);

@@ -151,3 +151,19 @@ def test_full_size_1024_properties(gpu):
     assert abs(r.get_max() - 0.75) <= 2e-6 and abs(r.get_min() - 0.75) <= 2e-6
     assert r.get_num_elements_reduced() == n ** 3
     a.end_solution()
+
+
+def test_auto_tuner_picks_a_variant_and_preserves_data(gpu):
+    """run_auto_tuner_now() (yk_solution_api.hpp:880) times the compiled tile shapes on the real vars and must leave
+    their contents untouched; the solution then runs with the chosen shape and still matches the oracle."""
+    size, steps = (64, 48, 160), 3
+    ref = O.run_iso3dfd(size, steps)
+    _, _, soln = make(size)
+    before = domain_slice(soln, soln.get_var("p"), 1).copy()
+    soln.run_auto_tuner_now(False)
+    assert np.array_equal(domain_slice(soln, soln.get_var("p"), 1), before)
+    chosen = soln.get_kernel_variant(0)
+    assert chosen in soln.get_kernel_variant_names(0) and not chosen.startswith("abl") and chosen != "naive"
+    soln.run_solution(0, steps - 1)
+    assert O.rel_linf(domain_slice(soln, soln.get_var("p"), steps), ref[("p", steps)]) <= TOL
+    soln.end_solution()

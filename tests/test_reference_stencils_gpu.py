@@ -77,3 +77,20 @@ def test_reference_test_stencil_matches_reference(gpu, name):
                 got = np.asarray(_slice(s2, s2.get_var(vname), int(t)), dtype=np.float64)
                 ref = z[key].astype(np.float64)
                 assert np.abs(got - ref).max() / max(1e-30, np.abs(ref).max()) <= 2e-5, (vn, key)
+
+
+def test_generic_registry_defaults_are_specialised_and_spill_free(gpu):
+    """csrc/stencil_generic.hip picks kernels per part at compile time; prepare_solution() never selects a shape
+    whose kernel spilled registers (hipFuncGetAttributes localSizeBytes > 0)."""
+    from yask_amd import yk_factory
+    expect = {"iso3dfd_sponge": "starlin", "ssg2": "march", "test_3d": "march", "cube": "march", "test_boundary_3d": "naive"}
+    for stencil, family in expect.items():
+        fac = yk_factory(stencil)
+        s = fac.new_solution(fac.new_env())
+        s.set_overall_domain_size_vec([64, 64, 64])
+        s.prepare_solution()
+        for part in range(s.get_num_parts()):
+            names = s.get_kernel_variant_names(part)
+            chosen = s.get_kernel_variant(part)
+            assert s.get_kernel_variant_scratch_bytes(part, names.index(chosen)) == 0, (stencil, chosen)
+        assert s.get_kernel_variant(s.get_num_parts() - 1).startswith(family), (stencil, s.get_kernel_variant(s.get_num_parts() - 1))

@@ -480,6 +480,16 @@ namespace yask {
                     os << "\n";
                 }
                 os << "    };\n";
+                // which groups are vars over ALL domain dims (they share strides and pads; the marching kernels
+                // address them with one common offset, other vars through their own strides)
+                os << "    static constexpr bool group_full[" << em.groups.size() << "] = {";
+                for (size_t g = 0; g < em.groups.size(); g++) {
+                    int nd = 0;
+                    for (auto& dim : em.groups[g].var->get_dims())
+                        if (dim->get_type() == DOMAIN_INDEX) nd++;
+                    os << (g ? ", " : "") << (nd == nddims ? "true" : "false");
+                }
+                os << "};\n";
                 os << "    static constexpr int n_reads = " << em.reads.size() << ";\n"
                       "    static constexpr ReadOff reads[" << (em.reads.size() ? em.reads.size() : 1) << "] = {";
                 for (size_t i = 0; i < em.reads.size(); i++) {

@@ -1,12 +1,55 @@
-// stencil_generic.hip -- kernel registry for ANY solution the `cdna4_hip` compiler target can render:
-// every part gets the always-legal naive kernel and, for 3-D solutions, the vector-per-thread kernel.
+// stencil_generic.hip -- kernel registry for ANY solution the `cdna4_hip` compiler target can render.
+// Every part gets the always-legal point kernel; 3-D parts without sub-domain conditions also get, when
+// eligible (decided at compile time from the generated part): the vector-per-thread kernel, the generic
+// marching kernel (all offset-read and written groups are full-dim vars, slabs fit the LDS, <= 32 groups) and
+// the linear-star kernel (the compiler found the linear star form).  Default = the most specialised one.
 // Compiled once per stencil with -DYKH_GEN_HEADER="gen/<name>_cdna4_hip.hpp" -DYKH_GEN_NS=ykh_gen_<name>
-// (Makefile: GENERIC_STENCILS).  Hand-tuned registries (stencil_iso3dfd.hip, stencil_3axis.hip,
-// stencil_ssg.hip) add the marching kernels for the hot-path stencils.
+// (Makefile: GENERIC_STENCILS).  The hand-tuned registries (stencil_iso3dfd.hip, stencil_3axis.hip,
+// stencil_ssg.hip) list more tile shapes for the hot-path stencils.
 #include YKH_GEN_HEADER
 #include "ykh_stencil_tu.hpp"
 
 namespace ykh {
+
+template <class P>
+constexpr bool starlin_eligible() {
+    if constexpr (!P::has_lin) return false;
+    else {
+        if (P::has_domain_cond || !P::group_full[P::lin_group]) return false;
+        for (int i = 0; i < P::n_writes; i++)
+            if (!P::group_full[P::writes[i]]) return false;
+        return P::n_groups <= 16;
+    }
+}
+
+template <class P>
+void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
+    typedef typename P::real_t T;
+    constexpr int VZ = 16 / (int)sizeof(T);
+    PartImpl p;
+    p.meta = meta;
+    p.variants.push_back(naive_variant<P>());
+    if (ndd == 3) {
+        if constexpr (!P::has_domain_cond) {
+            p.variants.push_back(vecpt_variant<P, VZ, 64, 4, 1>());
+            p.default_variant = (int)p.variants.size() - 1;
+            if constexpr (march_eligible<P>() && P::n_groups <= 32) {
+                // 8-byte lanes keep the per-thread queue state small (ykh_march.hpp); tile 128 x 8
+                if constexpr (MarchCfg<P, 2, 64, 8>::lds_bytes <= 160 * 1024) {
+                    p.variants.push_back(march_variant<P, 2, 64, 8, 2>());
+                    p.default_variant = (int)p.variants.size() - 1;
+                }
+            }
+            if constexpr (starlin_eligible<P>()) {
+                p.variants.push_back(starlin_variant<P, VZ, 32, 16, 1, ROT_MOVE, 1, 2, 4>());
+                p.default_variant = (int)p.variants.size() - 1;
+                p.variants.push_back(starlin_variant<P, VZ, 32, 16, 2, ROT_MOVE, 1, 2, 4>());
+            }
+        }
+    }
+    s.parts.push_back(p);
+}
+
 const SolnImpl& ykh_solution_impl() {
     using namespace YKH_GEN_NS;
     static const SolnImpl impl = [] {
@@ -15,17 +58,7 @@ const SolnImpl& ykh_solution_impl() {
         int ndd = 0;
         for (int i = 0; i < soln.ndims; i++) ndd += (dims[i].type == DIM_DOMAIN);
         int pi = 0;
-#define YKH_ADD_PART(PART)                                                                      \
-        {                                                                                           \
-            PartImpl p;                                                                             \
-            p.meta = &parts[pi++];                                                                  \
-            p.variants.push_back(naive_variant<PART>());                                            \
-            if (ndd == 3 && !PART::has_domain_cond) {                                               \
-                p.variants.push_back(vecpt_variant<PART, 16 / (int)sizeof(real_t), 64, 4, 1>());    \
-                p.default_variant = 1;                                                              \
-            }                                                                                       \
-            s.parts.push_back(p);                                                                   \
-        }
+#define YKH_ADD_PART(PART) add_part<PART>(s, &parts[pi++], ndd);
         YKH_FOR_EACH_PART(YKH_ADD_PART)
 #undef YKH_ADD_PART
         return s;

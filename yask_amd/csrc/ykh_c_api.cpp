@@ -323,6 +323,14 @@ const char* yk_solution_get_kernel_variant_name(yk_soln_h s, int part, int i) {
     return so.impl.parts[part].variants[i].name;
     YK_CATCH("")
 }
+yk_idx_t yk_solution_get_kernel_variant_scratch_bytes(yk_soln_h s, int part, int i) {
+    YK_TRY
+    Solution& so = S(s);
+    if (part < 0 || part >= (int)so.impl.parts.size()) YKH_THROW("part index out of range");
+    if (i < 0 || i >= (int)so.impl.parts[part].variants.size()) YKH_THROW("variant index out of range");
+    return (yk_idx_t)variant_scratch_bytes(so.impl.parts[part].variants[i]);
+    YK_CATCH(-1)
+}
 int yk_solution_time_part(yk_soln_h s, int part, int variant, yk_idx_t xchunk, yk_idx_t t, int reps, float* ms) {
     YK_TRY
     Solution& so = S(s);

@@ -46,6 +46,19 @@ constexpr GroupShape group_shape(int g) {
     return s;
 }
 
+// A part can use the marching kernel if every group that is read at an offset (queue or slab) and every
+// written group is a var over all domain dims (shared strides/pads); centre-only operands may be partial.
+template <class P>
+constexpr bool march_eligible() {
+    if (P::has_domain_cond) return false;
+    for (int g = 0; g < P::n_groups; g++) {
+        GroupShape s = group_shape<P>(g);
+        bool offs = s.xlo || s.xhi || s.ylo || s.yhi || s.zlo || s.zhi || s.mixed;
+        if ((offs || s.written) && !P::group_full[g]) return false;
+    }
+    return true;
+}
+
 // Per-group layout tables, computed once per instantiation at compile time (always used through
 // constexpr values: a call in a runtime context would put the analysis loops into the kernel).
 struct MarchTab {

@@ -48,7 +48,10 @@ struct KernelVariant {
     void (*launch)(const PartArgs& a, dim3 grid, hipStream_t s);
     int vz = 0;            // elements per thread along z (0: one 16-byte vector)
     int rx = 0;            // >0: not a marching kernel; a block handles rx consecutive x planes (vecpt)
+    const void* func = nullptr;   // the __global__ symbol (for hipFuncGetAttributes: scratch use = register spills)
 };
+// bytes of scratch (private segment) per thread of a variant's kernel; > 0 means hipcc spilled registers
+size_t variant_scratch_bytes(const KernelVariant& kv);
 struct PartImpl {
     const PartMeta* meta;
     std::vector<KernelVariant> variants;   // variants[0] is the always-legal naive kernel

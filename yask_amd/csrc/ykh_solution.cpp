@@ -58,6 +58,13 @@ long long Env::sum_over_ranks(long long v) const { return env_reduce(*this, 0, v
 long long Env::min_over_ranks(long long v) const { return env_reduce(*this, 1, v); }
 long long Env::max_over_ranks(long long v) const { return env_reduce(*this, 2, v); }
 
+size_t variant_scratch_bytes(const KernelVariant& kv) {
+    if (!kv.func) return 0;
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, kv.func) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return at.localSizeBytes;
+}
+
 // ------------------------------------------------------------------ Solution basics
 Solution::Solution(std::shared_ptr<Env> e, const SolnImpl& im) : env(e), impl(im), meta(im.meta) {
     ndd = 0;
@@ -392,6 +399,11 @@ void Solution::prepare() {
                 YKH_THROW("unknown -hip_variant '" + variant_override + "'; available:" + names);
             }
         }
+        if (variant_override.empty() && !force_scalar) {
+            // a default whose kernel spilled registers into scratch is never worth it (measured 1.4-6x slower):
+            // fall back to the next less specialised shape that did not
+            while (v > 0 && variant_scratch_bytes(pi.variants[v]) > 0) v--;
+        }
         if (variant_override.empty() && !force_scalar && ndd == 3 && pi.variants[v].star && pi.variants[v].rx == 0) {
             // Small grids: the default (largest) tile can leave most CUs without a workgroup.  Among the
             // compiled tile shapes of the same kernel family pick the one that fills the most CUs (ties: the
@@ -418,6 +430,7 @@ void Solution::prepare() {
                     const std::string kn = kv.name;
                     if (!kv.star || kv.rx > 0 || kn.compare(0, 3, "abl") == 0 || kn.compare(0, family.size(), family) != 0) continue;
                     if (kn.find("_pd2") != std::string::npos || kn.find("_cd2") != std::string::npos || kn.find("_hl") != std::string::npos) continue;
+                    if (variant_scratch_bytes(kv) > 0) continue;
                     double sc = score_of(kv);
                     idx_t area = (idx_t)kv.tz * kv.ty;
                     if (sc > best * 1.001 || (sc > best * 0.999 && area > best_area)) { best = sc; best_area = area; v = (int)k; }
@@ -697,6 +710,7 @@ void Solution::run_auto_tuner_now() {
         for (size_t k = 0; k < pi.variants.size(); k++) {
             if (!pi.variants[k].star && pi.variants.size() > 1 && !force_scalar) continue;   // naive only as last resort
             if (std::strncmp(pi.variants[k].name, "abl", 3) == 0) continue;                   // profiling ablations
+            if (variant_scratch_bytes(pi.variants[k]) > 0) continue;                          // spilled registers
             std::vector<idx_t> chunks = {0};
             if (pi.variants[k].star) { chunks.push_back(rb.hi[0] - rb.lo[0]); chunks.push_back(256); chunks.push_back(128); }
             for (idx_t xc : chunks) {

@@ -259,13 +259,26 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
         static_for<NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             if constexpr (g != SG && analyze_group<P>(g).any) {
-                const T* gp = (const T*)a.ptr[g] + pc;
-                static_for<RY>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    if constexpr (ABL & 2) cen[CS][g][j] = V(1);
-                    else if constexpr (NT_STREAMS) cen[CS][g][j] = ldv_b_nt<V>(gp, roff[j]);
-                    else cen[CS][g][j] = ldv_b<V>(gp, roff[j]);
-                });
+                if constexpr (P::group_full[g]) {
+                    const T* gp = (const T*)a.ptr[g] + pc;
+                    static_for<RY>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        if constexpr (ABL & 2) cen[CS][g][j] = V(1);
+                        else if constexpr (NT_STREAMS) cen[CS][g][j] = ldv_b_nt<V>(gp, roff[j]);
+                        else cen[CS][g][j] = ldv_b<V>(gp, roff[j]);
+                    });
+                } else {
+                    // var over a subset of the domain dims (e.g. the 1-D sponge coefficients of iso3dfd_sponge):
+                    // own strides (0 for a missing dim); without the unit-stride dim the value is broadcast
+                    const int xg = (int)((pc - org) / a.sx);      // plane index (uniform)
+                    static_for<RY>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        const int y = clampi(yt0 + ly * RY + j, a.ay0, a.ay1 - 1);
+                        const T* gp = (const T*)a.ptr[g] + (idx_t)xg * a.gsx[g] + (idx_t)y * a.gsy[g];
+                        if (a.gsz[g] == 0) cen[CS][g][j] = V(gp[0]);
+                        else cen[CS][g][j] = ldv<V>(gp + zc);
+                    });
+                }
             }
         });
     };

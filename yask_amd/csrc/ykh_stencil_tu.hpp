@@ -32,7 +32,9 @@ void launch_star(const PartArgs& a, dim3 grid, hipStream_t s) {
 
 template <class P>
 KernelVariant naive_variant() {
-    return KernelVariant{"naive", false, 64, 4, 0, 256, &launch_naive<P>};
+    KernelVariant kv{"naive", false, 64, 4, 0, 256, &launch_naive<P>};
+    kv.func = reinterpret_cast<const void*>(&naive_kernel<P>);
+    return kv;
 }
 
 // ABL != 0 variants compute WRONG results on purpose (profiling ablations); their names start with
@@ -43,7 +45,9 @@ KernelVariant star_variant() {
     static const std::string name = std::string(ABL ? "abl" + std::to_string(ABL) + "_" : "") + "star25d_z" +
                                     std::to_string(C::TZ) + "_y" + std::to_string(C::TY) + "_r" +
                                     std::to_string(RY) + (ROT == ROT_UNROLL ? "_u" : "_m");
-    return KernelVariant{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_star<P, TZL, TYL, RY, ROT, ABL>};
+    KernelVariant kv{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_star<P, TZL, TYL, RY, ROT, ABL>};
+    kv.func = reinterpret_cast<const void*>(&star25d_kernel<P, TZL, TYL, RY, ROT, ABL>);
+    return kv;
 }
 
 template <class P, int VZ, int TZL, int TYL, int RY, int ROT, int NTH, int MINW, int CH, int ABL = 0>
@@ -70,6 +74,7 @@ KernelVariant vecpt_variant() {
     KernelVariant kv{name.c_str(), true, TZL * VZ, TYL, 0, TZL * TYL, &launch_vecpt<P, VZ, TZL, TYL, RX>};
     kv.vz = VZ;
     kv.rx = RX;
+    kv.func = reinterpret_cast<const void*>(&vecpt_kernel<P, VZ, TZL, TYL, RX>);
     return kv;
 }
 
@@ -93,6 +98,7 @@ KernelVariant march_variant() {
                                     std::to_string(C::TY) + (RY > 1 ? "_r" + std::to_string(RY) : "") + (PIN ? "_pin" : "") + (PD > 1 ? "_pd" + std::to_string(PD) : "") + "_w" + std::to_string(MINW);
     KernelVariant kv{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_march<P, VZ, TZL, TYL, MINW, RY, PIN, PD>};
     kv.vz = VZ;
+    kv.func = reinterpret_cast<const void*>(&march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD>);
     return kv;
 }
 
@@ -108,6 +114,7 @@ KernelVariant starlin_variant() {
                                     std::to_string(MINW) + "_c" + std::to_string(CH);
     KernelVariant kv{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_starlin<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL>};
     kv.vz = VZ;
+    kv.func = reinterpret_cast<const void*>(&starlin_kernel<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL>);
     return kv;
 }
 

@@ -368,6 +368,9 @@ class yk_solution:
             n += 1
 
     def get_kernel_variant(self, part=0): return self._lib.call("yk_solution_get_kernel_variant", self._h, part).decode()
+    def get_kernel_variant_scratch_bytes(self, part, i):
+        return self._lib.call("yk_solution_get_kernel_variant_scratch_bytes", self._h, int(part), int(i))
+
     def get_kernel_variant_names(self, part=0):
         n = self._lib.call("yk_solution_get_num_kernel_variants", self._h, part)
         return [self._lib.call("yk_solution_get_kernel_variant_name", self._h, part, i).decode() for i in range(n)]
