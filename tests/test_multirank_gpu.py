@@ -103,6 +103,7 @@ def _single(stencil, g, steps, opts):
 
 
 @pytest.mark.parametrize("nr,opts", [((2, 1, 1), ""), ((1, 1, 2), ""), ((1, 2, 1), "-no-overlap_comms"),
+                                     ((2, 1, 1), "-no-hip_direct_halo"),      # packed path for the x faces too
                                      ((2, 1, 1), "-min_exterior 12 -hip_variant star25d_z128_y16_r1_u")])
 def test_iso3dfd_two_ranks_equal_one_rank(gpu, nr, opts):
     g, steps = (48, 40, 72), 4

@@ -51,6 +51,18 @@ void Solution::alloc_halo_buffers() {
         }
         x->send_cap = sb * elem_bytes();
         x->recv_cap = rb * elem_bytes();
+        // in-place transfer? (decided from geometry only, so both ends of a link agree)
+        x->direct = direct_halo && ndd == 3 && nb.ofs[0] != 0 && nb.ofs[1] == 0 && nb.ofs[2] == 0 &&
+                    x->send.size() == x->recv.size() && !x->send.empty();
+        for (auto* lst : {&x->send, &x->recv})
+            for (const Slab& sl : *lst) {
+                const Var& v = *vars[sl.var];
+                if (!(v.uses_domain[0] && v.uses_domain[1] && v.uses_domain[2]) || v.l1_norm > 1 || v.misc_elems != 1)
+                    x->direct = false;
+            }
+        for (size_t i = 0; x->direct && i < x->send.size(); i++)
+            if (x->send[i].var != x->recv[i].var) x->direct = false;      // asymmetric halos: keep the packed path
+        if (x->direct) { xfers.push_back(std::move(x)); continue; }
         if (x->send_cap) YKH_HIP(hipMalloc(&x->send_buf, x->send_cap));
         if (x->recv_cap) YKH_HIP(hipMalloc(&x->recv_buf, x->recv_cap));
         if (x->send_cap || x->recv_cap) xfers.push_back(std::move(x));
@@ -115,6 +127,29 @@ void Solution::exchange_halos(idx_t /*t_written*/, int /*stage*/, bool start_onl
         YKH_HIP(hipEventRecord(ev_a, compute_stream));
         YKH_HIP(hipStreamWaitEvent(comm_stream, ev_a, 0));
         for (auto& x : xfers) {
+            if (x->direct) {
+                // one message per dirty (var, slot): whole planes (with their y/z pads) straight from / into the var
+                x->send_now = x->recv_now = 0;
+                for (size_t i = 0; i < x->send.size(); i++) {
+                    const Slab &ss = x->send[i], &rs = x->recv[i];
+                    Var& v = *vars[ss.var];
+                    for (int slot = 0; slot < v.nslots; slot++) {
+                        if (!v.dirty[slot]) continue;
+                        auto plane_ptr = [&](idx_t xl) {
+                            return (char*)v.dptr + ((size_t)slot * v.slot_elems + v.origin_elems + xl * v.stride[0] -
+                                                    v.pad_l[1] * v.stride[1] - v.pad_l[2] * v.stride[2]) * elem_bytes();
+                        };
+                        HaloMsg m;
+                        m.peer = x->nb.rank;
+                        m.send_buf = plane_ptr(ss.lo[0]); m.send_bytes = (size_t)(ss.n[0] * v.stride[0]) * elem_bytes();
+                        m.recv_buf = plane_ptr(rs.lo[0]); m.recv_bytes = (size_t)(rs.n[0] * v.stride[0]) * elem_bytes();
+                        m.tag = (x->nb.ofs[0] + 1) * 9 + 4;
+                        msgs.push_back(m);
+                        x->send_now += m.send_bytes; x->recv_now += m.recv_bytes;
+                    }
+                }
+                continue;
+            }
             x->send_now = move_slabs(*this, x->send, x->send_buf, true, comm_stream);
             // receive size: same rule evaluated on my recv slabs (neighbour's dirty flags mirror mine)
             size_t r = 0;
@@ -141,7 +176,7 @@ void Solution::exchange_halos(idx_t /*t_written*/, int /*stage*/, bool start_onl
         if (env->exch_wait && env->exch_wait(env->user, (int)msgs.size(), msgs.data(), (void*)comm_stream) != 0)
             YKH_THROW("halo-exchange transport failed while waiting");
         for (auto& x : xfers)
-            if (x->recv_now) move_slabs(*this, x->recv, x->recv_buf, false, comm_stream);
+            if (x->recv_now && !x->direct) move_slabs(*this, x->recv, x->recv_buf, false, comm_stream);
         YKH_HIP(hipEventRecord(ev_b, comm_stream));
         YKH_HIP(hipStreamWaitEvent(compute_stream, ev_b, 0));
         for (auto& v : vars) v->set_dirty_all(false);

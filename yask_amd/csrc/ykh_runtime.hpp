@@ -250,6 +250,7 @@ public:
     bool overlap_comms = true;
     bool step_wrap = false;        // set_step_wrap(): any step index is accepted and wrapped onto the slots
     idx_t min_exterior = 0;
+    bool direct_halo = true;       // -[no-]hip_direct_halo: in-place transfer of contiguous x-face halos
     idx_t overlap_splits = 4;      // -hip_overlap_splits: interior launches per stage when overlapping comms
     bool do_halo_exchange = true;
     bool auto_tune = false;        // tuned at prepare() when true
@@ -338,6 +339,9 @@ struct NeighborXfer {
     void* recv_buf = nullptr;
     size_t send_cap = 0, recv_cap = 0;   // bytes
     size_t send_now = 0, recv_now = 0;   // bytes in the current exchange
+    // x-only neighbour and every slab belongs to a full-dim var read face-only: the slab's planes, taken with
+    // their y/z pads, are ONE contiguous range of the var -> send/receive in place, no pack/unpack kernels
+    bool direct = false;
 };
 
 std::string version_string();

@@ -185,7 +185,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
     const char* bool_opts[] = {"overlap_comms", "use_shm", "use_device_mpi", "force_scalar_exchange", "force_scalar",
                                "bind_inner_threads", "bundle_allocs", "init_scratch_vars", "auto_tune",
                                "allow_addl_padding", "round_up_temporal_angles", "print_suffixes", "verbose",
-                               "exchange_halos", "auto_tune_each_stage", "trace"};
+                               "exchange_halos", "auto_tune_each_stage", "trace", "hip_direct_halo"};
     const char* int_opts[] = {"hip_overlap_splits", "min_exterior", "max_threads", "outer_threads", "inner_threads", "numa_pref",
                               "auto_tune_radius", "thread_divisor", "block_threads", "hip_xchunk", "device_thread_limit"};
     const char* dbl_opts[] = {"auto_tune_trial_secs"};
@@ -208,6 +208,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                     else if (b == "force_scalar") { force_scalar = val; }
                     else if (b == "auto_tune") auto_tune = val;
                     else if (b == "trace") env->trace = val;
+                    else if (b == "hip_direct_halo") { direct_halo = val; invalidate(); }
                     else ignored_opts[b] = val ? "true" : "false";
                 }
         }
