@@ -668,8 +668,8 @@ void Solution::run(idx_t first_step, idx_t last_step) {
 // ------------------------------------------------------------------ stats (soln_apis.cpp:349-562)
 Stats Solution::get_stats() {
     Stats s = stats;
-    idx_t pts = 1, lpts = 1;
-    for (int d = 0; d < ndd; d++) { pts *= global_size[d]; lpts *= local_size[d]; }
+    idx_t pts = 1;
+    for (int d = 0; d < ndd; d++) pts *= global_size[d];
     s.num_elements = pts;
     idx_t reads = 0, writes = 0, fpops = 0;
     for (auto& p : impl.parts) {
