@@ -107,6 +107,8 @@ def _single(stencil, g, steps, opts):
                                      ((2, 1, 1), "-min_exterior 12 -hip_variant star25d_z128_y16_r1_u")])
 def test_iso3dfd_two_ranks_equal_one_rank(gpu, nr, opts):
     g, steps = (48, 40, 72), 4
+    # bit-exactness needs one kernel everywhere: keep thin y/z exterior slabs on the marching kernel here
+    opts = (opts + " -no-hip_thin_slab_point_kernel").strip()
     two = _two_ranks("iso3dfd", g, steps, opts, nr)
     one = _single("iso3dfd", g, steps, opts)
     assert np.array_equal(two["p"], one["p"])
@@ -125,6 +127,15 @@ def test_ssg_two_ranks_equal_one_rank(gpu):
         assert np.array_equal(two[n], one[n]), n
         r = ref[(n, steps)].astype(np.float64)
         assert np.abs(two[n].astype(np.float64) - r).max() / max(1e-30, np.abs(r).max()) <= 2e-5, n
+
+
+def test_thin_exterior_slabs_on_the_point_kernel(gpu):
+    """Default for y/z decompositions: exterior slabs much thinner than a marching tile are computed by the point
+    kernel (different summation order -> compare with the stated tolerance, not bit-exactly)."""
+    g, steps = (40, 48, 96), 3
+    two = _two_ranks("iso3dfd", g, steps, "", (1, 1, 2))
+    ref = O.run_iso3dfd(g, steps)[("p", steps)]
+    assert O.rel_linf(two["p"], ref) <= 2e-5
 
 
 def test_axis3_two_ranks_y_split(gpu):

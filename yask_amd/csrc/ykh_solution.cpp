@@ -185,7 +185,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
     const char* bool_opts[] = {"overlap_comms", "use_shm", "use_device_mpi", "force_scalar_exchange", "force_scalar",
                                "bind_inner_threads", "bundle_allocs", "init_scratch_vars", "auto_tune",
                                "allow_addl_padding", "round_up_temporal_angles", "print_suffixes", "verbose",
-                               "exchange_halos", "auto_tune_each_stage", "trace", "hip_direct_halo"};
+                               "exchange_halos", "auto_tune_each_stage", "trace", "hip_direct_halo", "hip_thin_slab_point_kernel"};
     const char* int_opts[] = {"hip_overlap_splits", "min_exterior", "max_threads", "outer_threads", "inner_threads", "numa_pref",
                               "auto_tune_radius", "thread_divisor", "block_threads", "hip_xchunk", "device_thread_limit"};
     const char* dbl_opts[] = {"auto_tune_trial_secs"};
@@ -209,6 +209,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                     else if (b == "auto_tune") auto_tune = val;
                     else if (b == "trace") env->trace = val;
                     else if (b == "hip_direct_halo") { direct_halo = val; invalidate(); }
+                    else if (b == "hip_thin_slab_point_kernel") thin_slab_point_kernel = val;
                     else ignored_opts[b] = val ? "true" : "false";
                 }
         }
@@ -560,7 +561,17 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
 void Solution::launch_part(int part, idx_t t, const Box& box, hipStream_t s) {
     const PartMeta& pm = *impl.parts[part].meta;
     if (pm.step_cond && !pm.step_cond(t)) return;            // IF_STEP: the part is idle this step
-    if (!pm.is_scratch) { launch_part_variant(part, part_variant[part], part_xchunk[part], t, box, s); return; }
+    if (!pm.is_scratch) {
+        int v = part_variant[part];
+        const KernelVariant& kv = impl.parts[part].variants[v];
+        // Thin exterior slabs of a y/z decomposition (8 points wide against a 128 x 32 tile) would keep 1/16 of a
+        // marching tile's lanes busy: such boxes go to the point kernel (always variant 0).
+        if (thin_slab_point_kernel && kv.star && kv.rx == 0 && ndd == 3 && !box.empty() &&
+            ((box.hi[2] - box.lo[2]) * 4 <= kv.tz || (box.hi[1] - box.lo[1]) * 4 <= kv.ty))
+            v = 0;
+        launch_part_variant(part, v, part_xchunk[part], t, box, s);
+        return;
+    }
     // scratch part: evaluate over the box grown by the halo of the scratch var(s) it writes, so that the
     // parts reading them at offsets find every value (the reference does this per micro-block,
     // src/kernel/lib/stencil_calc.cpp:40-289; here the scratch var is a whole device array)
