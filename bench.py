@@ -80,6 +80,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="iso3dfd", choices=sorted(WORKLOADS), help="default: the headline (BASELINE.json configs[1])")
     ap.add_argument("--size", type=int, default=0, help="points per GPU in each dim (default: the workload's configured size)")
+    ap.add_argument("--decomp", default="xslab", choices=["xslab", "compact"],
+                    help="xslab (default): N x 1 x 1 ranks, contiguous whole-plane faces, 2 neighbours per GPU; compact: the "
+                         "reference's default most-compact rank grid (8 -> 2x2x2), as in BASELINE.json configs[3]")
+    ap.add_argument("--points-per-gpu", dest="local", type=int, nargs=3, default=None, metavar=("NX", "NY", "NZ"),
+                    help="points per GPU per dim (overrides --size), e.g. --decomp compact --points-per-gpu 1024 1024 512")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"])
     ap.add_argument("--opts", default="", help="extra yask options, e.g. '-hip_variant NAME'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -96,9 +101,11 @@ def main():
     env, transport = ydist.new_env(fac, args.transport)
     soln = fac.new_solution(env)
     n = args.size or dflt_n
-    # x-slab decomposition: x-faces are whole contiguous planes and each GPU has only 2 neighbours
-    soln.set_num_ranks_vec([world, 1, 1])
-    soln.set_rank_domain_size_vec([n, n, n])
+    local = list(args.local) if args.local else [n, n, n]
+    if args.decomp == "xslab":
+        # x-slab decomposition: x-faces are whole contiguous planes and each GPU has only 2 neighbours
+        soln.set_num_ranks_vec([world, 1, 1])
+    soln.set_rank_domain_size_vec(local)
     if args.opts:
         rem = soln.apply_command_line_options(args.opts)
         assert rem == "", rem
@@ -127,7 +134,8 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
-    pts_per_gpu = float(n) ** 3
+    pts_per_gpu = float(local[0]) * local[1] * local[2]
+    grid = soln.get_num_ranks_vec()
     total_pts = pts_per_gpu * world
     value = total_pts * args.steps / elapsed * 1e-9
 
@@ -138,7 +146,7 @@ def main():
     achieved = BYTES_PER_POINT * pts_per_gpu / (kern_ms * 1e-3) * 1e-9
     traffic = None
     tf = ROOT / "profiles" / "hbm_traffic.json"
-    if tf.exists() and args.workload == "iso3dfd" and n == 1024:
+    if tf.exists() and args.workload == "iso3dfd" and local == [1024, 1024, 1024]:
         try:
             traffic = json.load(open(tf)).get("iso3dfd_1024_bytes_per_launch")
         except Exception:  # noqa: BLE001
@@ -150,8 +158,12 @@ def main():
             "value": round(value, 3), "unit": "Gpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic (logical-index hash init, random-like)",
-            "config": {"workload": f"{descr}, {n}^3 points per GPU, global {n * world}x{n}x{n}",
-                       "decomposition": f"x-slabs {world}x1x1", "halo_transport": transport,
+            "config": {"workload": f"{descr}, {local[0]}x{local[1]}x{local[2]} points per GPU" if args.local else
+                                   f"{descr}, {n}^3 points per GPU, global {n * world}x{n}x{n}",
+                       "decomposition": (f"x-slabs {world}x1x1" if args.decomp == "xslab" else
+                                         "rank grid " + "x".join(str(g) for g in grid) + ", global " +
+                                         "x".join(str(g * l) for g, l in zip(grid, local))),
+                       "halo_transport": transport,
                        "kernel": "+".join(soln.get_kernel_variant(p) for p in range(nparts)), "overlap_comms": True},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
