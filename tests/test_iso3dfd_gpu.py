@@ -153,6 +153,21 @@ def test_full_size_1024_properties(gpu):
     a.end_solution()
 
 
+@pytest.mark.parametrize("opt", ["-hip_round_launches", "-no-hip_round_launches"])
+def test_more_tiles_than_cus(gpu, opt):
+    """A plane of 9 x 32 = 288 tiles on 256 CUs: by default the tile rows are launched one CU-filling round at a
+    time (-hip_round_launches); either way the result equals the point kernel's."""
+    size, steps = (12, 1024, 1100), 2
+    _, _, a = make(size, opt)
+    assert a.get_kernel_variant(0).startswith("starlin")
+    _, _, b = make(size, "-force_scalar")
+    a.run_solution(0, steps - 1)
+    b.run_solution(0, steps - 1)
+    assert a.compare_data(b, 1e-4) == 0
+    a.end_solution()
+    b.end_solution()
+
+
 def test_auto_tuner_picks_a_variant_and_preserves_data(gpu):
     """run_auto_tuner_now() (yk_solution_api.hpp:880) times the compiled tile shapes on the real vars and must leave
     their contents untouched; the solution then runs with the chosen shape and still matches the oracle."""

@@ -250,6 +250,7 @@ public:
     bool overlap_comms = true;
     bool step_wrap = false;        // set_step_wrap(): any step index is accepted and wrapped onto the slots
     idx_t min_exterior = 0;
+    bool round_launches = true;           // -[no-]hip_round_launches: one launch per CU-filling round of tile rows
     bool thin_slab_point_kernel = true;   // -[no-]hip_thin_slab_point_kernel: thin y/z exterior slabs use the point kernel
     bool direct_halo = true;       // -[no-]hip_direct_halo: in-place transfer of contiguous x-face halos
     idx_t overlap_splits = 4;      // -hip_overlap_splits: interior launches per stage when overlapping comms

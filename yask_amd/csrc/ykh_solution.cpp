@@ -185,7 +185,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
     const char* bool_opts[] = {"overlap_comms", "use_shm", "use_device_mpi", "force_scalar_exchange", "force_scalar",
                                "bind_inner_threads", "bundle_allocs", "init_scratch_vars", "auto_tune",
                                "allow_addl_padding", "round_up_temporal_angles", "print_suffixes", "verbose",
-                               "exchange_halos", "auto_tune_each_stage", "trace", "hip_direct_halo", "hip_thin_slab_point_kernel"};
+                               "exchange_halos", "auto_tune_each_stage", "trace", "hip_direct_halo", "hip_thin_slab_point_kernel", "hip_round_launches"};
     const char* int_opts[] = {"hip_overlap_splits", "min_exterior", "max_threads", "outer_threads", "inner_threads", "numa_pref",
                               "auto_tune_radius", "thread_divisor", "block_threads", "hip_xchunk", "device_thread_limit"};
     const char* dbl_opts[] = {"auto_tune_trial_secs"};
@@ -210,6 +210,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                     else if (b == "trace") env->trace = val;
                     else if (b == "hip_direct_halo") { direct_halo = val; invalidate(); }
                     else if (b == "hip_thin_slab_point_kernel") thin_slab_point_kernel = val;
+                    else if (b == "hip_round_launches") round_launches = val;
                     else ignored_opts[b] = val ? "true" : "false";
                 }
         }
@@ -548,6 +549,23 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
         xc = std::max<idx_t>(1, std::min(xc, nx));
         a.xchunk = (int)xc;
         a.nxc = (int)ceil_div(nx, xc);
+        if (round_launches) {
+            // More tiles than CUs: one launch per round of whole tile rows, so that the tiles of a round start
+            // together and march in step (neighbouring tiles then touch the same DRAM pages and L2 lines at
+            // about the same time; tiles of a second round started one by one drift apart).
+            const idx_t per_row = (idx_t)a.ntz * a.nxc, cus = std::max(1, env->num_cus);
+            const idx_t rows = cus / per_row;
+            // (only when that does not add rounds: 100 tiles per row would give 200-block launches)
+            if (per_row * a.nty > cus && rows >= 1 && ceil_div((idx_t)a.nty, rows) <= ceil_div(per_row * a.nty, cus)) {
+                for (idx_t y0 = box.lo[1]; y0 < box.hi[1]; y0 += rows * kv.ty) {
+                    Box sub = box;
+                    sub.lo[1] = y0;
+                    sub.hi[1] = std::min(y0 + rows * kv.ty, box.hi[1]);
+                    launch_part_variant(part, variant, xc, t, sub, s);
+                }
+                return;
+            }
+        }
         dim3 grid((unsigned)((idx_t)a.ntz * a.nty * a.nxc), 1, 1);
         kv.launch(a, grid, s);
     } else {
