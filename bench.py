@@ -88,7 +88,13 @@ def main():
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"])
     ap.add_argument("--opts", default="", help="extra yask options, e.g. '-hip_variant NAME'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    # yask options start with '-': hand "--opts '-hip_variant X'" to argparse as "--opts=-hip_variant X"
+    argv = sys.argv[1:]
+    for i in range(len(argv) - 1):
+        if argv[i] == "--opts":
+            argv[i:i + 2] = ["--opts=" + argv[i + 1]]
+            break
+    args = ap.parse_args(argv)
 
     import torch
     from yask_amd import yk_factory, dist as ydist

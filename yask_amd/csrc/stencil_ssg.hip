@@ -7,6 +7,8 @@
 namespace ykh {
 void ssg_variants_k1(PartImpl&);   // marching kernels, stage 1
 void ssg_variants_k2(PartImpl&);   // marching kernels, stage 2
+void ssg_variants_k3(PartImpl&);   // more shapes, stage 1
+void ssg_variants_k4(PartImpl&);   // more shapes, stage 2
 
 const SolnImpl& ykh_solution_impl() {
     using namespace ykh_gen_ssg;
@@ -23,7 +25,8 @@ const SolnImpl& ykh_solution_impl() {
             p.variants.push_back(vecpt_variant<part_1, 4, 64, 4, 4>());
             p.variants.push_back(vecpt_variant<part_1, 2, 64, 4, 2>());
             ssg_variants_k1(p);
-            p.set_default("march_v2_z128_y8_pd2_w2");
+            ssg_variants_k3(p);
+            p.set_default("march_v4_z256_y8_w2");
             s.parts.push_back(p);
         }
         {
@@ -36,7 +39,8 @@ const SolnImpl& ykh_solution_impl() {
             p.variants.push_back(vecpt_variant<part_2, 4, 64, 4, 4>());
             p.variants.push_back(vecpt_variant<part_2, 2, 64, 4, 2>());
             ssg_variants_k2(p);
-            p.set_default("march_v2_z128_y8_pd2_w2");
+            ssg_variants_k4(p);
+            p.set_default("march_v4_z256_y8_w2");
             s.parts.push_back(p);
         }
         return s;

@@ -1,0 +1,14 @@
+// stencil_ssg_k3.hip -- more marching-kernel shapes for ssg part_1 (rows per thread, 16-byte lanes, deeper prefetch).
+#include "gen/ssg_cdna4_hip.hpp"
+#include "ykh_stencil_tu.hpp"
+namespace ykh {
+using namespace ykh_gen_ssg;
+void ssg_variants_k3(PartImpl& p) {
+    p.variants.push_back(march_variant<part_1, 2, 64, 8, 2, 2, false, 1>());   // two rows per thread: tile 128x16
+    p.variants.push_back(march_variant<part_1, 2, 64, 8, 2, 2, false, 2>());
+    p.variants.push_back(march_variant<part_1, 4, 32, 16, 2, 1, false, 1>());  // 16-byte lanes, tile 128x16
+    p.variants.push_back(march_variant<part_1, 4, 64, 8, 2, 1, false, 1>());   // 16-byte lanes, tile 256x8
+    p.variants.push_back(march_variant<part_1, 2, 64, 8, 2, 1, false, 3>());   // three planes ahead
+    p.variants.push_back(march_variant<part_1, 2, 64, 8, 4, 1, false, 1>());   // <= 128 VGPRs: two workgroups per CU
+}
+}  // namespace ykh

@@ -8,7 +8,8 @@
 //                       groups get row/column halos only), double buffered, one barrier per plane;
 //                       the slab interior is written from the queue's centre entry, the halo from
 //                       per-thread prefetch registers;
-//   * mixed offsets  -> (rare: ssg's `mu`) direct aligned global loads, as in ykh_vecpt.hpp.
+//   * mixed offsets  -> (rare: ssg's `mu`) one (possibly unaligned) global vector load per read, requested with
+//                       the rest of the plane's prefetch, i.e. PD planes before it is used.
 // A workgroup owns a (y,z) tile and marches along x, so x re-use lives in registers and never depends
 // on cache capacity: the point kernels re-fetch every x-neighbour plane over the fabric
 // (ssg stage 1: ~124 B/point moved for 52 B/point algorithmic), this kernel moves each plane once
@@ -20,6 +21,8 @@
 #include "ykh_starlin.hpp"   // vecn, zshiftn, ldv/stv, nt variants
 
 namespace ykh {
+
+constexpr int MAX_MIXED = 8;      // more mixed-offset reads than this (e.g. the 5x5x5 `cube`) are loaded where they are used
 
 struct GroupShape {
     int xlo, xhi, ylo, yhi, zlo, zhi;   // ranges over axis-aligned reads
@@ -67,6 +70,7 @@ struct MarchTab {
     int yl[MAX_GROUPS], yh[MAX_GROUPS], zlv[MAX_GROUPS], zhv[MAX_GROUPS], lp[MAX_GROUPS], lrows[MAX_GROUPS];
     int soff[MAX_GROUPS + 1];
     int nhy[MAX_GROUPS], nh[MAX_GROUPS], nht[MAX_GROUPS], hoff[MAX_GROUPS + 1];
+    int nmix, mix[MAX_MIXED][4];        // distinct mixed-offset reads (g, dx, dy, dz)
 };
 
 template <class P, int VZ_, int TZL_, int TYL_, int RY_ = 1>
@@ -94,12 +98,29 @@ struct MarchCfg {
             t.hoff[g] = ho; ho += t.nht[g];
         }
         t.qoff[NG] = qo; t.soff[NG] = so; t.hoff[NG] = ho;
+        for (int i = 0; i < P::n_reads; i++) {
+            int g = P::reads[i].g, dx = P::reads[i].dx, dy = P::reads[i].dy, dz = P::reads[i].dz;
+            if ((dx != 0) + (dy != 0) + (dz != 0) < 2) continue;
+            bool seen = false;
+            for (int k = 0; k < t.nmix; k++)
+                if (t.mix[k][0] == g && t.mix[k][1] == dx && t.mix[k][2] == dy && t.mix[k][3] == dz) seen = true;
+            if (seen) continue;
+            if (t.nmix == MAX_MIXED) { t.nmix = 0; break; }      // too many to hold in registers: no prefetch
+            t.mix[t.nmix][0] = g; t.mix[t.nmix][1] = dx; t.mix[t.nmix][2] = dy; t.mix[t.nmix][3] = dz;
+            t.nmix++;
+        }
         return t;
+    }
+    static constexpr int mix_index(int g, int dx, int dy, int dz) {
+        for (int k = 0; k < tab.nmix; k++)
+            if (tab.mix[k][0] == g && tab.mix[k][1] == dx && tab.mix[k][2] == dy && tab.mix[k][3] == dz) return k;
+        return -1;
     }
     static constexpr MarchTab tab = make();
     static constexpr int NQTOT = tab.qoff[NG];
     static constexpr int SLAB_TOT = tab.soff[NG];           // elements of one buffer set
     static constexpr int NHTOT = tab.hoff[NG];
+    static constexpr int NMIX = tab.nmix;
     static constexpr size_t lds_bytes = sizeof(T) * 2 * (SLAB_TOT > 0 ? SLAB_TOT : 1);
 };
 
@@ -112,6 +133,7 @@ struct MarchAcc {
     static constexpr int VZ = C::VZ;
     const PartArgs& a;
     const V (&q)[C::NQTOT > 0 ? C::NQTOT : 1];     // queues of the row being evaluated
+    const V (&mx)[C::NMIX > 0 ? C::NMIX : 1];      // mixed-offset reads of the row, prefetched
     const T* sb;            // current slab buffer set
     int ly, lz;             // row (within the tile) and z lane of the point
     int x, y, z0;           // point (first of the VZ)
@@ -119,8 +141,12 @@ struct MarchAcc {
     template <int G, int DX, int DY, int DZ>
     __device__ __forceinline__ V rd() const {
         constexpr int nz = (DX != 0) + (DY != 0) + (DZ != 0);
-        if constexpr (nz > 1) {
-            // mixed offset: aligned global loads (L1/L2 served)
+        if constexpr (nz > 1 && C::NMIX > 0) {
+            constexpr int k = C::mix_index(G, DX, DY, DZ);
+            static_assert(k >= 0, "mixed read missing from the table");
+            return mx[k];
+        } else if constexpr (nz > 1) {
+            // many mixed offsets: aligned global loads at the point of use (L1/L2 served)
             const T* p = (const T*)a.ptr[G] + (idx_t)(x + DX) * a.gsx[G] + (idx_t)(y + DY) * a.gsy[G];
             constexpr int qq = (DZ >= 0) ? DZ / VZ : -((-DZ + VZ - 1) / VZ);
             constexpr int e = DZ - qq * VZ;
@@ -183,14 +209,24 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
     const int myz = zt0 + lz * VZ;
     const int myy0 = yt0 + ly * RY;       // first of this thread's RY rows
 
-    // own-point offsets within a plane (vars lacking a dim have stride 0), clamped into the allocation
+    // Own-point offsets within a plane, clamped into the allocation.  Vars over all domain dims share strides
+    // and pads, so one 32-bit byte offset from the plane's first allocated element serves every such group and
+    // the accesses take the scalar-base + 32-bit-offset form (no per-group strides in SGPRs, no 64-bit vector
+    // adds); vars over a subset of the dims (centre-only operands) go through their own strides.
     int yc[RY];
     static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; yc[j] = clampi(myy0 + j, a.ay0, a.ay1 - 1); });
     const int zc = clampi(myz, a.az0, a.az1 - VZ);
     auto xclamp = [&](int x) { return clampi(x, a.ax0, a.ax1 - 1); };
+    const idx_t org = (idx_t)a.ay0 * a.sy + a.az0;
+    auto xplane = [&](int x) -> idx_t { return org + (idx_t)xclamp(x) * a.sx; };     // uniform
+    auto plane_off = [&](int y, int z) -> unsigned {                                   // y, z inside the allocation
+        return (unsigned)((y - a.ay0) * (int)a.sy + (z - a.az0)) * (unsigned)sizeof(T);
+    };
+    unsigned ooff[RY];
+    static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; ooff[j] = plane_off(yc[j], zc); });
 
     // halo assignments: for group g, halo vector h = tid + k*NT
-    int hofs[C::NHTOT > 0 ? C::NHTOT : 1];       // (y,z) part of the global offset (gsz is 1 for slab groups)
+    unsigned hofs[C::NHTOT > 0 ? C::NHTOT : 1];       // byte offset within the plane
     int hlds[C::NHTOT > 0 ? C::NHTOT : 1];
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
@@ -216,22 +252,36 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
                 if (h >= NH) { row = 0; zv = 0; }
                 int y = clampi(yt0 - YL + row, a.ay0, a.ay1 - 1);
                 int z = clampi(zt0 - ZLV * VZ + zv * VZ, a.az0, a.az1 - VZ);
-                hofs[HO + k] = y * (int)a.gsy[g] + z;
+                hofs[HO + k] = plane_off(y, z);
                 hlds[HO + k] = (h < NH) ? SO + row * LP + zv * VZ : -1;
             });
         }
+    });
+    // mixed-offset reads: the (y+dy, z+dz) part of each read's address, per row
+    unsigned moff[RY][C::NMIX > 0 ? C::NMIX : 1];
+    static_for<C::NMIX>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int DY = C::tab.mix[k][2], DZ = C::tab.mix[k][3];
+        static_for<RY>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            moff[j][k] = plane_off(clampi(myy0 + j + DY, a.ay0, a.ay1 - 1), clampi(myz + DZ, a.az0, a.az1 - VZ));
+        });
     });
 
     V q[RY][C::NQTOT > 0 ? C::NQTOT : 1];
     V nxt[PD][RY][NG];
     V hreg[PD][C::NHTOT > 0 ? C::NHTOT : 1];
+    V mreg[PD][RY][C::NMIX > 0 ? C::NMIX : 1];
 
     // load the own-point vector of group g, row j, at plane x (vars without z: broadcast)
     auto ld_own = [&](auto gc, int j, int x) -> V {
         constexpr int g = decltype(gc)::value;
-        const T* p = (const T*)a.ptr[g] + (idx_t)xclamp(x) * a.gsx[g] + (idx_t)yc[j] * a.gsy[g];
-        if (a.gsz[g] == 0) return V(p[0]);
-        return ldv<V>(p + zc);
+        if constexpr (P::group_full[g]) return ldv_b<V>(sbase((const T*)a.ptr[g] + xplane(x)), ooff[j]);
+        else {
+            const T* p = (const T*)a.ptr[g] + (idx_t)xclamp(x) * a.gsx[g] + (idx_t)yc[j] * a.gsy[g];
+            if (a.gsz[g] == 0) return V(p[0]);
+            return ldv<V>(p + zc);
+        }
     };
     auto prefetch = [&](int x, auto sc) {      // everything needed to advance to centre plane x, into register set S
         constexpr int S = decltype(sc)::value;
@@ -243,12 +293,23 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
                 static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; nxt[S][j][g] = ld_own(gc, j, x + XHI); });
             if constexpr (slabg) {
                 constexpr int NHT = C::tab.nht[g], HO = C::tab.hoff[g];
-                const T* p = (const T*)a.ptr[g] + (idx_t)xclamp(x) * a.gsx[g];
+                auto p = sbase((const T*)a.ptr[g] + xplane(x));
                 static_for<NHT>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
-                    hreg[S][HO + k] = ldv<V>(p + hofs[HO + k]);
+                    hreg[S][HO + k] = ldv_b<V>(p, hofs[HO + k]);
                 });
             }
+        });
+    };
+    // the mixed-offset reads of centre plane x (their registers are read by eval(), so plane x's set is refilled
+    // only after plane x has been evaluated)
+    auto prefetch_mixed = [&](int x, auto sc) {
+        constexpr int S = decltype(sc)::value;
+        static_for<C::NMIX>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int g = C::tab.mix[k][0], DX = C::tab.mix[k][1];
+            auto p = sbase((const T*)a.ptr[g] + xplane(x + DX));
+            static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; mreg[S][j][k] = ldv_u<V>(p, moff[j][k]); });
         });
     };
 
@@ -261,7 +322,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
             static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; q[j][QO + i] = ld_own(gc, j, xs + XLO + i); });
         });
     });
-    static_for<PD>([&](auto sc) { prefetch(xs + decltype(sc)::value, sc); });
+    static_for<PD>([&](auto sc) { prefetch(xs + decltype(sc)::value, sc); prefetch_mixed(xs + decltype(sc)::value, sc); });
 
     // One centre plane; `sc` = register set holding its prefetched data (the plane's position in the trip).
     auto plane = [&](int x, auto sc) {
@@ -293,21 +354,25 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
             constexpr int j = decltype(jc)::value;
             const int myy = myy0 + j;
             V out[MAX_GROUPS];
-            MarchAcc<C, P, PIN> acc{a, q[j], sb, ly * RY + j, lz, x, myy, myz, out};
+            MarchAcc<C, P, PIN> acc{a, q[j], mreg[S][j], sb, ly * RY + j, lz, x, myy, myz, out};
             P::eval(acc);
             if (x < xe && myy < a.y1 && myz < a.z1 && myz + VZ > a.z0) {
+                // (written groups are vars over all dims; the store predicate implies yc[j] == myy, zc == myz)
+                const idx_t xo = org + (idx_t)x * a.sx;
+                const bool whole = myz >= a.z0 && myz + VZ <= a.z1;
                 static_for<P::n_writes>([&](auto wc) {
                     constexpr int g = P::writes[decltype(wc)::value];
-                    T* op = (T*)a.ptr[g] + (idx_t)x * a.gsx[g] + (idx_t)myy * a.gsy[g] + myz;
-                    if (myz >= a.z0 && myz + VZ <= a.z1) stv<V>(op, out[g]);
+                    auto ob = sbase((T*)a.ptr[g] + xo);
+                    if (whole) stv_b<V>(ob, ooff[j], out[g]);
                     else
                         static_for<VZ>([&](auto ec) {
                             constexpr int e = decltype(ec)::value;
-                            if (myz + e >= a.z0 && myz + e < a.z1) op[e] = out[g][e];
+                            if (myz + e >= a.z0 && myz + e < a.z1) stv_b<T>(ob, ooff[j] + e * (unsigned)sizeof(T), out[g][e]);
                         });
                 });
             }
         });
+        prefetch_mixed(x + PD, sc);
         // rotate the queues
         static_for<NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value;

@@ -145,11 +145,42 @@ struct LinAcc {
 // Keep `v` (and, through the memory clobber, later memory reads) at this point of the program order.
 template <class V> __device__ __forceinline__ void pin_reg(V& v) { asm volatile("" : "+v"(v) : : "memory"); }
 template <class V, typename T> __device__ __forceinline__ V ldv(const T* p) { return *reinterpret_cast<const V*>(p); }
+// A uniform pointer made opaque in an SGPR pair: stops hipcc from re-associating `base + plane + lane_offset` into
+// a loop-invariant 64-bit *vector* pointer `base + lane_offset` per access group (2 VGPRs each, plus a 64-bit
+// vector add per access) -- the accesses below then keep the scalar-base form.
+// (the pointer leaves as a global-address-space pointer: the asm would otherwise hide that from hipcc and the
+// accesses would become flat_load/flat_store)
+#define YKH_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ YKH_GLOBAL T* sbase(T* p) {
+    YKH_GLOBAL T* g = (YKH_GLOBAL T*)p;
+    asm volatile("" : "+s"(g));
+    return g;
+}
 // uniform base + 32-bit unsigned byte offset (selects the saddr form of global_load/store)
 template <class V, typename T> __device__ __forceinline__ V ldv_b(const T* base, unsigned byte_off) {
     return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + byte_off); }
+// (the lane offset is made opaque at the point of use as well, so that its zero-extension stays in the basic
+// block of the access: instruction selection only forms `global_load v, v_off, s[base]` when it sees both)
+__device__ __forceinline__ unsigned voff(unsigned o) { asm volatile("" : "+v"(o)); return o; }
+template <class V, typename T> __device__ __forceinline__ V ldv_b(YKH_GLOBAL const T* base, unsigned byte_off) {
+    byte_off = voff(byte_off);
+    return *(YKH_GLOBAL const V*)((YKH_GLOBAL const char*)base + byte_off); }
+// same, for an address that is only element-aligned (global memory takes multi-dword loads at dword alignment)
+template <class V, typename T> __device__ __forceinline__ V ldv_u(YKH_GLOBAL const T* base, unsigned byte_off) {
+    typedef V __attribute__((aligned(sizeof(T)))) VU;
+    byte_off = voff(byte_off);
+    return *(YKH_GLOBAL const VU*)((YKH_GLOBAL const char*)base + byte_off); }
 template <class V, typename T> __device__ __forceinline__ void stv_b(T* base, unsigned byte_off, V v) {
     *reinterpret_cast<V*>(reinterpret_cast<char*>(base) + byte_off) = v; }
+template <class V, typename T> __device__ __forceinline__ void stv_b(YKH_GLOBAL T* base, unsigned byte_off, V v) {
+    byte_off = voff(byte_off);
+    *(YKH_GLOBAL V*)((YKH_GLOBAL char*)base + byte_off) = v; }
+template <class V, typename T> __device__ __forceinline__ void stv_b_nt(YKH_GLOBAL T* base, unsigned byte_off, V v) {
+    byte_off = voff(byte_off);
+    __builtin_nontemporal_store(v, (YKH_GLOBAL V*)((YKH_GLOBAL char*)base + byte_off)); }
+template <class V, typename T> __device__ __forceinline__ V ldv_b_nt(YKH_GLOBAL const T* base, unsigned byte_off) {
+    byte_off = voff(byte_off);
+    return __builtin_nontemporal_load((YKH_GLOBAL const V*)((YKH_GLOBAL const char*)base + byte_off)); }
 template <class V, typename T> __device__ __forceinline__ void stv_b_nt(T* base, unsigned byte_off, V v) {
     __builtin_nontemporal_store(v, reinterpret_cast<V*>(reinterpret_cast<char*>(base) + byte_off)); }
 template <class V, typename T> __device__ __forceinline__ V ldv_b_nt(const T* base, unsigned byte_off) {
@@ -260,7 +291,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
             constexpr int g = decltype(gc)::value;
             if constexpr (g != SG && analyze_group<P>(g).any) {
                 if constexpr (P::group_full[g]) {
-                    const T* gp = (const T*)a.ptr[g] + pc;
+                    auto gp = sbase((const T*)a.ptr[g] + pc);
                     static_for<RY>([&](auto jc) {
                         constexpr int j = decltype(jc)::value;
                         if constexpr (ABL & 2) cen[CS][g][j] = V(1);
@@ -284,12 +315,12 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
     };
     auto load_interior = [&](int x, auto sc) {
         constexpr int S = decltype(sc)::value;
-        const T* pp = sp + xplane(x);
+        auto pp = sbase(sp + xplane(x));
         static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; nxt[S][j] = ldv_b<V>(pp, roff[j]); });
     };
     auto load_halo = [&](int x, auto sc) {
         constexpr int S = decltype(sc)::value;
-        const T* pp = sp + xplane(x);
+        auto pp = sbase(sp + xplane(x));
         static_for<NHT>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             if constexpr (ABL & 1) hreg[S][k] = V(0); else hreg[S][k] = ldv_b<V>(pp, hoff[k]);
@@ -300,7 +331,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
     // and the first arriving plane xs with its halos.
     static_for<NP - 1>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        const T* pp = sp + xplane(xs - (NP - 1) + i);
+        auto pp = sbase(sp + xplane(xs - (NP - 1) + i));
         static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; pq[i][j] = ldv_b<V>(pp, roff[j]); });
     });
     static_for<NA>([&](auto ic) {
@@ -460,15 +491,14 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
                 // points inside the box are never clamped, so roff[j] is also the store offset
                 static_for<P::n_writes>([&](auto wc) {
                     constexpr int g = P::writes[decltype(wc)::value];
-                    T* ob = (T*)a.ptr[g] + ((idx_t)xo * a.sx + org);          // uniform
+                    auto ob = sbase((T*)a.ptr[g] + ((idx_t)xo * a.sx + org));          // uniform
                     if constexpr (ABL & 4) { if (out[g][0] == T(123.456)) ob[0] = out[g][0]; }
                     else if (myz >= a.z0 && myz + VZ <= a.z1) {
                         if constexpr (NT_STREAMS) stv_b_nt<V>(ob, roff[j], out[g]); else stv_b<V>(ob, roff[j], out[g]);
                     } else {
-                        T* op = reinterpret_cast<T*>(reinterpret_cast<char*>(ob) + roff[j]);
                         static_for<VZ>([&](auto ec) {
                             constexpr int e = decltype(ec)::value;
-                            if (myz + e >= a.z0 && myz + e < a.z1) op[e] = out[g][e];
+                            if (myz + e >= a.z0 && myz + e < a.z1) stv_b<T>(ob, roff[j] + e * (unsigned)sizeof(T), out[g][e]);
                         });
                     }
                 });
