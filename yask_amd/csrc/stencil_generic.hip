@@ -39,10 +39,10 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
                     p.variants.push_back(march_variant<P, 2, 64, 8, 2>());
                     p.default_variant = (int)p.variants.size() - 1;
                 }
-                // 16-byte lanes, tile 256 x 8: fastest where the state still fits 256 VGPRs (ssg: +6 %);
-                // prepare_solution() steps back to the shape above when this one spilled
-                if constexpr (VZ > 2 && MarchCfg<P, VZ, 64, 8>::lds_bytes <= 160 * 1024) {
-                    p.variants.push_back(march_variant<P, VZ, 64, 8, 2>());
+                // 16-byte lanes, tile 128 x 16, one-touch streams non-temporal: fastest where the state still fits
+                // 256 VGPRs (ssg: +12 %); prepare_solution() steps back to the shape above when this one spilled
+                if constexpr (VZ > 2 && MarchCfg<P, VZ, 32, 16>::lds_bytes <= 160 * 1024) {
+                    p.variants.push_back(march_variant<P, VZ, 32, 16, 2, 1, false, 1, 1>());
                     p.default_variant = (int)p.variants.size() - 1;
                 }
             }

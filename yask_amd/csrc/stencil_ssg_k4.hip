@@ -10,5 +10,8 @@ void ssg_variants_k4(PartImpl& p) {
     p.variants.push_back(march_variant<part_2, 4, 64, 8, 2, 1, false, 1>());   // 16-byte lanes, tile 256x8
     p.variants.push_back(march_variant<part_2, 2, 64, 8, 2, 1, false, 3>());   // three planes ahead
     p.variants.push_back(march_variant<part_2, 2, 64, 8, 4, 1, false, 1>());   // <= 128 VGPRs: two workgroups per CU
+    p.variants.push_back(march_variant<part_2, 4, 64, 8, 2, 1, false, 1, 1>());   // + non-temporal one-touch streams
+    p.variants.push_back(march_variant<part_2, 4, 32, 16, 2, 1, false, 1, 1>());
+    p.variants.push_back(march_variant<part_2, 2, 64, 8, 2, 1, false, 2, 1>());
 }
 }  // namespace ykh

@@ -71,6 +71,7 @@ struct MarchTab {
     int soff[MAX_GROUPS + 1];
     int nhy[MAX_GROUPS], nh[MAX_GROUPS], nht[MAX_GROUPS], hoff[MAX_GROUPS + 1];
     int nmix, mix[MAX_MIXED][4];        // distinct mixed-offset reads (g, dx, dy, dz)
+    bool in_mix[MAX_GROUPS];            // the group is read at a mixed offset
 };
 
 template <class P, int VZ_, int TZL_, int TYL_, int RY_ = 1>
@@ -98,6 +99,8 @@ struct MarchCfg {
             t.hoff[g] = ho; ho += t.nht[g];
         }
         t.qoff[NG] = qo; t.soff[NG] = so; t.hoff[NG] = ho;
+        for (int i = 0; i < P::n_reads; i++)
+            if ((P::reads[i].dx != 0) + (P::reads[i].dy != 0) + (P::reads[i].dz != 0) > 1) t.in_mix[P::reads[i].g] = true;
         for (int i = 0; i < P::n_reads; i++) {
             int g = P::reads[i].g, dx = P::reads[i].dx, dy = P::reads[i].dy, dz = P::reads[i].dz;
             if ((dx != 0) + (dy != 0) + (dz != 0) < 2) continue;
@@ -181,8 +184,10 @@ struct MarchAcc {
     __device__ __forceinline__ V step() const { return V(T(a.t)); }
 };
 
-// PD: planes prefetched ahead (1 or 2; 2 = two alternating register sets, twice the bytes in flight).
-template <class P, int VZ, int TZL, int TYL, int MINW, int RY = 1, bool PIN = false, int PD = 1>
+// PD: planes prefetched ahead (1..3; PD alternating register sets, PD times the bytes in flight).
+// NTS: non-temporal loads of the centre-only operands (read once, by one thread) and non-temporal stores, so that
+// these streams do not push the halo lines -- which a neighbouring tile is about to read -- out of L2.
+template <class P, int VZ, int TZL, int TYL, int MINW, int RY = 1, bool PIN = false, int PD = 1, int NTS = 0>
 __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a) {
     typedef MarchCfg<P, VZ, TZL, TYL, RY> C;
     typedef typename C::T T;
@@ -276,7 +281,11 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
     // load the own-point vector of group g, row j, at plane x (vars without z: broadcast)
     auto ld_own = [&](auto gc, int j, int x) -> V {
         constexpr int g = decltype(gc)::value;
-        if constexpr (P::group_full[g]) return ldv_b<V>(sbase((const T*)a.ptr[g] + xplane(x)), ooff[j]);
+        if constexpr (P::group_full[g]) {
+            constexpr bool once = C::tab.nq[g] == 1 && !C::tab.slab[g] && !C::tab.in_mix[g];
+            if constexpr (NTS && once) return ldv_b_nt<V>(sbase((const T*)a.ptr[g] + xplane(x)), ooff[j]);
+            else return ldv_b<V>(sbase((const T*)a.ptr[g] + xplane(x)), ooff[j]);
+        }
         else {
             const T* p = (const T*)a.ptr[g] + (idx_t)xclamp(x) * a.gsx[g] + (idx_t)yc[j] * a.gsy[g];
             if (a.gsz[g] == 0) return V(p[0]);
@@ -363,7 +372,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
                 static_for<P::n_writes>([&](auto wc) {
                     constexpr int g = P::writes[decltype(wc)::value];
                     auto ob = sbase((T*)a.ptr[g] + xo);
-                    if (whole) stv_b<V>(ob, ooff[j], out[g]);
+                    if (whole) { if constexpr (NTS) stv_b_nt<V>(ob, ooff[j], out[g]); else stv_b<V>(ob, ooff[j], out[g]); }
                     else
                         static_for<VZ>([&](auto ec) {
                             constexpr int e = decltype(ec)::value;

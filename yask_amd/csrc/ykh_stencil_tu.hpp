@@ -78,27 +78,27 @@ KernelVariant vecpt_variant() {
     return kv;
 }
 
-template <class P, int VZ, int TZL, int TYL, int MINW, int RY = 1, bool PIN = false, int PD = 1>
+template <class P, int VZ, int TZL, int TYL, int MINW, int RY = 1, bool PIN = false, int PD = 1, int NT = 0>
 void launch_march(const PartArgs& a, dim3 grid, hipStream_t s) {
     typedef MarchCfg<P, VZ, TZL, TYL, RY> C;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD>), grid, dim3(C::NT), C::lds_bytes, s, a);
+    hipLaunchKernelGGL((march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT>), grid, dim3(C::NT), C::lds_bytes, s, a);
 }
-// Generic marching kernel (ykh_march.hpp). Name: march_v<VZ>_z<tile z>_y<tile y>_w<min waves/SIMD>
-template <class P, int VZ, int TZL, int TYL, int MINW, int RY = 1, bool PIN = false, int PD = 1>
+// Generic marching kernel (ykh_march.hpp). Name: march_v<VZ>_z<tile z>_y<tile y>[_r<rows>][_pin][_pd<planes ahead>][_nt]_w<min waves/SIMD>
+template <class P, int VZ, int TZL, int TYL, int MINW, int RY = 1, bool PIN = false, int PD = 1, int NT = 0>
 KernelVariant march_variant() {
     typedef MarchCfg<P, VZ, TZL, TYL, RY> C;
     static_assert(C::lds_bytes <= 160 * 1024, "march tile does not fit the 160 KiB LDS");
     static const std::string name = "march_v" + std::to_string(VZ) + "_z" + std::to_string(C::TZ) + "_y" +
-                                    std::to_string(C::TY) + (RY > 1 ? "_r" + std::to_string(RY) : "") + (PIN ? "_pin" : "") + (PD > 1 ? "_pd" + std::to_string(PD) : "") + "_w" + std::to_string(MINW);
-    KernelVariant kv{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_march<P, VZ, TZL, TYL, MINW, RY, PIN, PD>};
+                                    std::to_string(C::TY) + (RY > 1 ? "_r" + std::to_string(RY) : "") + (PIN ? "_pin" : "") + (PD > 1 ? "_pd" + std::to_string(PD) : "") + (NT ? "_nt" : "") + "_w" + std::to_string(MINW);
+    KernelVariant kv{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_march<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT>};
     kv.vz = VZ;
-    kv.func = reinterpret_cast<const void*>(&march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD>);
+    kv.func = reinterpret_cast<const void*>(&march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT>);
     return kv;
 }
 
