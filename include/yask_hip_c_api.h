@@ -168,6 +168,12 @@ const char* yk_solution_get_kernel_variant_name(yk_soln_h s, int part, int i);
 /* bytes of scratch per thread of variant i's kernel (> 0: the compiler spilled registers; such shapes are never
  * chosen by default or by the auto-tuner) */
 yk_idx_t yk_solution_get_kernel_variant_scratch_bytes(yk_soln_h s, int part, int i);
+/* Bounding box, inside this rank's domain, of part `part`'s sub-domain (IF_DOMAIN) condition, found by
+ * prepare_solution() as the reference's find_bounding_box() does (src/kernel/lib/setup.cpp:1082-1169); the part is
+ * only ever launched inside it.  first/last: 3 rank-local indices each (last inclusive).  Returns 1 if the part has
+ * such a box, 0 if it is unconditional (first/last = the rank's domain), 2 if the condition holds nowhere in this
+ * rank (first > last), -1 on error. */
+int yk_solution_get_part_bounding_box(yk_soln_h s, int part, yk_idx_t* first, yk_idx_t* last);
 /* Launch part `part` of step t once with variant i (or the selected one if i < 0) on the compute
  * stream, bracketed by HIP events; returns the kernel duration in ms in *ms. Used by bench.py. */
 int yk_solution_time_part(yk_soln_h s, int part, int variant, yk_idx_t xchunk, yk_idx_t t, int reps, float* ms);

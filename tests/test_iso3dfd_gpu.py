@@ -178,7 +178,8 @@ def test_auto_tuner_picks_a_variant_and_preserves_data(gpu):
     soln.run_auto_tuner_now(False)
     assert np.array_equal(domain_slice(soln, soln.get_var("p"), 1), before)
     chosen = soln.get_kernel_variant(0)
-    assert chosen in soln.get_kernel_variant_names(0) and not chosen.startswith("abl") and chosen != "naive"
+    # (on a grid this small any family may win, the point kernel included)
+    assert chosen in soln.get_kernel_variant_names(0) and not chosen.startswith("abl")
     soln.run_solution(0, steps - 1)
     assert O.rel_linf(domain_slice(soln, soln.get_var("p"), steps), ref[("p", steps)]) <= TOL
     soln.end_solution()

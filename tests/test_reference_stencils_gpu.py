@@ -79,18 +79,59 @@ def test_reference_test_stencil_matches_reference(gpu, name):
                 assert np.abs(got - ref).max() / max(1e-30, np.abs(ref).max()) <= 2e-5, (vn, key)
 
 
-def test_generic_registry_defaults_are_specialised_and_spill_free(gpu):
-    """csrc/stencil_generic.hip picks kernels per part at compile time; prepare_solution() never selects a shape
-    whose kernel spilled registers (hipFuncGetAttributes localSizeBytes > 0)."""
+def test_generic_registry_picks_spill_free_and_fast_shapes(gpu):
+    """csrc/stencil_generic.hip registers, per part, every kernel family that is legal for it; prepare_solution()
+    times them once on the real sizes and keeps the fastest shape whose kernel did not spill registers
+    (hipFuncGetAttributes localSizeBytes > 0 is never chosen).  The choice must be within 1.5x of the best
+    time measured afterwards (timing noise)."""
     from yask_amd import yk_factory
-    expect = {"iso3dfd_sponge": "starlin", "ssg2": "march", "test_3d": "march", "cube": "march", "test_boundary_3d": "naive"}
-    for stencil, family in expect.items():
+    for stencil in ["iso3dfd_sponge", "ssg2", "test_3d", "cube", "test_boundary_3d", "awp_abc"]:
         fac = yk_factory(stencil)
         s = fac.new_solution(fac.new_env())
-        s.set_overall_domain_size_vec([64, 64, 64])
+        s.set_overall_domain_size_vec([128, 128, 128])
         s.prepare_solution()
         for part in range(s.get_num_parts()):
             names = s.get_kernel_variant_names(part)
             chosen = s.get_kernel_variant(part)
             assert s.get_kernel_variant_scratch_bytes(part, names.index(chosen)) == 0, (stencil, chosen)
-        assert s.get_kernel_variant(s.get_num_parts() - 1).startswith(family), (stencil, s.get_kernel_variant(s.get_num_parts() - 1))
+            times = {n: s.time_part(part=part, variant=i, t=0, reps=5) for i, n in enumerate(names)
+                     if s.get_kernel_variant_scratch_bytes(part, i) == 0}
+            assert times[chosen] <= 1.5 * min(times.values()) + 0.01, (stencil, part, chosen, times)
+        if stencil == "test_boundary_3d":     # conditions that do not fill their boxes: only the point kernel is legal
+            assert {s.get_kernel_variant(p) for p in range(s.get_num_parts())} == {"naive"}
+    # at 256^3 the marching kernels are 3x faster than the point kernel on the 16th-order star
+    fac = yk_factory("iso3dfd_sponge")
+    s = fac.new_solution(fac.new_env())
+    s.set_overall_domain_size_vec([256, 256, 256])
+    s.prepare_solution()
+    assert s.get_kernel_variant(0).split("_")[0] in ("starlin", "march"), s.get_kernel_variant(0)
+
+
+def test_sub_domain_parts_get_bounding_boxes(gpu):
+    """prepare_solution() finds, on the device, the bounding box of every IF_DOMAIN condition inside the rank
+    (the reference's find_bounding_box, setup.cpp:1082-1169) and launches the part only there.
+    test_boundary_3d (TestStencils.cpp:853-865): sd0 = x in [5, nx-4], y in [4, ny-7], z in [6, nz-5]; !sd0 touches
+    every face, so its box is the whole domain."""
+    from yask_amd import yk_factory
+    fac = yk_factory("test_boundary_3d")
+    s = fac.new_solution(fac.new_env())
+    n = (20, 18, 24)
+    s.set_overall_domain_size_vec(list(n))
+    s.prepare_solution()
+    boxes = [s.get_part_bounding_box(p) for p in range(s.get_num_parts())]
+    assert (1, [5, 4, 6], [n[0] - 4, n[1] - 7, n[2] - 5]) in boxes, boxes
+    assert (1, [0, 0, 0], [n[0] - 1, n[1] - 1, n[2] - 1]) in boxes, boxes
+    # an unconditional part reports kind 0 and the rank's domain
+    fac = yk_factory("test_3d")
+    s = fac.new_solution(fac.new_env())
+    s.set_overall_domain_size_vec([16, 16, 16])
+    s.prepare_solution()
+    assert s.get_part_bounding_box(0) == (0, [0, 0, 0], [15, 15, 15])
+    # awp_abc: the free-surface parts live in a few planes at the top of z
+    fac = yk_factory("awp_abc")
+    s = fac.new_solution(fac.new_env())
+    s.set_overall_domain_size_vec([24, 20, 28])
+    s.prepare_solution()
+    kinds = [s.get_part_bounding_box(p) for p in range(s.get_num_parts())]
+    thin = [b for b in kinds if b[0] == 1 and b[2][2] - b[1][2] + 1 <= 2]
+    assert thin, kinds

@@ -56,6 +56,7 @@ class Box(C.Structure):
 
 PROTOTYPES = {
     "yk_solution_get_kernel_variant_scratch_bytes": (idx_t, [_H, C.c_int, C.c_int]),
+    "yk_solution_get_part_bounding_box": (C.c_int, [_H, C.c_int, C.POINTER(idx_t), C.POINTER(idx_t)]),
     "yk_solution_clear_stats": (C.c_int, [_H]),
     "yk_solution_set_min_pad_size": (C.c_int, [_H, _S, idx_t]),
     "yk_solution_get_min_pad_size": (idx_t, [_H, _S]),

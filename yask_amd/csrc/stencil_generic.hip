@@ -15,7 +15,7 @@ template <class P>
 constexpr bool starlin_eligible() {
     if constexpr (!P::has_lin) return false;
     else {
-        if (P::has_domain_cond || !P::group_full[P::lin_group]) return false;
+        if (!P::group_full[P::lin_group]) return false;
         for (int i = 0; i < P::n_writes; i++)
             if (!P::group_full[P::writes[i]]) return false;
         return P::n_groups <= 16;
@@ -29,8 +29,12 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
     PartImpl p;
     p.meta = meta;
     p.variants.push_back(naive_variant<P>());
+    if constexpr (P::has_domain_cond) p.cond_bb = &launch_cond_bb<P>;
+    // Sub-domain parts get the same kernels: they do not evaluate the condition, and prepare_solution() selects
+    // them only when the condition holds at every point of its bounding box (a "solid" box, e.g. awp's
+    // below-the-surface updates); otherwise the point kernel runs.
     if (ndd == 3) {
-        if constexpr (!P::has_domain_cond) {
+        {
             p.variants.push_back(vecpt_variant<P, VZ, 64, 4, 1>());
             p.default_variant = (int)p.variants.size() - 1;
             if constexpr (march_eligible<P>() && P::n_groups <= 32) {
@@ -61,6 +65,7 @@ const SolnImpl& ykh_solution_impl() {
     static const SolnImpl impl = [] {
         SolnImpl s;
         s.meta = &soln;
+        s.select_by_timing = true;      // the per-part defaults below are a static guess (e.g. awp_abc: the point kernel wins)
         int ndd = 0;
         for (int i = 0; i < soln.ndims; i++) ndd += (dims[i].type == DIM_DOMAIN);
         int pi = 0;

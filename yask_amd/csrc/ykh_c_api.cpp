@@ -331,6 +331,17 @@ yk_idx_t yk_solution_get_kernel_variant_scratch_bytes(yk_soln_h s, int part, int
     return (yk_idx_t)variant_scratch_bytes(so.impl.parts[part].variants[i]);
     YK_CATCH(-1)
 }
+int yk_solution_get_part_bounding_box(yk_soln_h s, int part, yk_idx_t* first, yk_idx_t* last) {
+    YK_TRY
+    Solution& so = S(s);
+    if (part < 0 || part >= (int)so.impl.parts.size()) YKH_THROW("part index out of range");
+    if (!so.prepared) YKH_THROW("get_part_bounding_box() called without calling prepare_solution() first");
+    const bool has = (size_t)part < so.part_has_bb.size() && so.part_has_bb[part];
+    const Box b = has ? so.part_bb[part] : so.rank_box();
+    for (int d = 0; d < 3; d++) { first[d] = d < MAX_DOMAIN_DIMS ? b.lo[d] : 0; last[d] = d < MAX_DOMAIN_DIMS ? b.hi[d] - 1 : 0; }
+    return !has ? 0 : (b.empty() ? 2 : 1);
+    YK_CATCH(-1)
+}
 int yk_solution_time_part(yk_soln_h s, int part, int variant, yk_idx_t xchunk, yk_idx_t t, int reps, float* ms) {
     YK_TRY
     Solution& so = S(s);

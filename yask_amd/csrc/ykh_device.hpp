@@ -172,6 +172,38 @@ __global__ void __launch_bounds__(256) naive_kernel(const PartArgs a) {
     P::eval(acc);
 }
 
+// Bounding box of a sub-domain (IF_DOMAIN) condition over a box: out[0..2] = min x,y,z, out[3..5] = max x,y,z
+// (local indices) of the points where the condition holds, out[6..7] = their number (one 64-bit counter).
+// Counterpart of the reference's find_bounding_box() (src/kernel/lib/setup.cpp:1082-1169); run once by
+// prepare_solution(), after which the part is launched over its box only.
+template <class P>
+__global__ void __launch_bounds__(256) cond_bb_kernel(const PartArgs a, int* out) {
+    __shared__ int sm[7];
+    if (threadIdx.x < 7) sm[threadIdx.x] = threadIdx.x < 3 ? 0x7fffffff : (threadIdx.x < 6 ? (int)0x80000000 : 0);
+    __syncthreads();
+    int z = a.z0 + blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = a.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    int x = a.x0 + blockIdx.z;
+    bool on = false;
+    if constexpr (P::has_domain_cond) {
+        if (z < a.z1 && y < a.y1 && x < a.x1) {
+            NaiveAcc<P> acc{a, x, y, z};
+            on = P::cond(acc);
+        }
+    }
+    if (on) {
+        atomicMin(&sm[0], x); atomicMin(&sm[1], y); atomicMin(&sm[2], z);
+        atomicMax(&sm[3], x); atomicMax(&sm[4], y); atomicMax(&sm[5], z);
+        atomicAdd(&sm[6], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && sm[6] > 0) {
+        atomicMin(&out[0], sm[0]); atomicMin(&out[1], sm[1]); atomicMin(&out[2], sm[2]);
+        atomicMax(&out[3], sm[3]); atomicMax(&out[4], sm[4]); atomicMax(&out[5], sm[5]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&out[6]), (unsigned long long)sm[6]);
+    }
+}
+
 // ------------------------------------------------------------------ star25d kernel
 enum { ROT_MOVE = 0, ROT_UNROLL = 1 };
 

@@ -53,7 +53,6 @@ constexpr GroupShape group_shape(int g) {
 // written group is a var over all domain dims (shared strides/pads); centre-only operands may be partial.
 template <class P>
 constexpr bool march_eligible() {
-    if (P::has_domain_cond) return false;
     for (int g = 0; g < P::n_groups; g++) {
         GroupShape s = group_shape<P>(g);
         bool offs = s.xlo || s.xhi || s.ylo || s.yhi || s.zlo || s.zhi || s.mixed;

@@ -56,6 +56,8 @@ struct PartImpl {
     const PartMeta* meta;
     std::vector<KernelVariant> variants;   // variants[0] is the always-legal naive kernel
     int default_variant = 0;
+    // sub-domain (IF_DOMAIN) parts: launches cond_bb_kernel over the box of `a` (grid as for the naive kernel)
+    void (*cond_bb)(const PartArgs& a, dim3 grid, int* dev_out, hipStream_t s) = nullptr;
     void set_default(const char* name) {
         for (size_t i = 0; i < variants.size(); i++)
             if (std::string(variants[i].name) == name) { default_variant = (int)i; return; }
@@ -65,6 +67,7 @@ struct PartImpl {
 struct SolnImpl {
     const SolnMeta* meta;
     std::vector<PartImpl> parts;
+    bool select_by_timing = false;     // prepare_solution() times the legal shapes of each part once and keeps the fastest
 };
 // Defined once per stencil library (stencil_<name>.hip).
 const SolnImpl& ykh_solution_impl();
@@ -273,6 +276,13 @@ public:
     std::map<std::string, std::shared_ptr<Var>> var_map;
     std::vector<std::shared_ptr<Var>> scratch_vars;   // compiler-declared scratch vars: device arrays, not in the API
     std::vector<int> part_variant;                   // chosen variant per part
+    std::vector<Box> part_bb;                        // sub-domain parts: bounding box of the condition (local indices)
+    std::vector<char> part_has_bb, part_bb_solid;    // solid: the condition holds everywhere in the box
+    bool part_needs_predicate(int part) const {      // only the point kernel evaluates the condition per point
+        const PartMeta& pm = *impl.parts[part].meta;
+        if (!pm.has_domain_cond) return false;
+        return !((size_t)part < part_has_bb.size() && part_has_bb[part] && part_bb_solid[part]);
+    }
     std::vector<idx_t> part_xchunk;
     hipStream_t compute_stream = nullptr, comm_stream = nullptr;
     bool own_streams = false;
@@ -304,6 +314,7 @@ public:
     Stats get_stats();       // returns and clears, like soln_apis.cpp:349-562
     void reset_auto_tuner(bool enable);
     void run_auto_tuner_now();
+    void tune_variants(bool quick);
     idx_t compare_data(const Solution& ref, double epsilon) const;
     void copy_vars_to_device() {}
     void copy_vars_from_device() {}
@@ -312,7 +323,7 @@ public:
     // internals used by ykh_halo.cpp / tuner
     void setup_rank();
     void launch_part(int part, idx_t t, const Box& box, hipStream_t s);
-    void launch_part_variant(int part, int variant, idx_t xchunk, idx_t t, const Box& box, hipStream_t s);
+    void launch_part_variant(int part, int variant, idx_t xchunk, idx_t t, const Box& box_in, hipStream_t s);
     void fill_part_args(int part, idx_t t, const Box& box, PartArgs& a) const;
     void alloc_halo_buffers();
     void free_halo_buffers();

@@ -387,6 +387,43 @@ void Solution::prepare() {
         }
         have_interior = !interior_box.empty();
     }
+    // Sub-domain parts: bounding box of the condition inside this rank's domain (the reference's
+    // find_bounding_box, src/kernel/lib/setup.cpp:1082-1169); the part is then launched over box ∩ bb only --
+    // a free-surface condition `z == last_domain_index(z)` costs one plane instead of a sweep of the grid.
+    part_bb.assign(impl.parts.size(), rank_box());
+    part_has_bb.assign(impl.parts.size(), 0);
+    part_bb_solid.assign(impl.parts.size(), 0);
+    {
+        int* dbb = nullptr;
+        for (size_t p = 0; p < impl.parts.size(); p++) {
+            const PartImpl& pi = impl.parts[p];
+            if (!pi.cond_bb || !pi.meta->has_domain_cond || pi.meta->is_scratch) continue;
+            if (!dbb) YKH_HIP(hipMalloc(&dbb, 8 * sizeof(int)));
+            const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
+            YKH_HIP(hipMemcpyAsync(dbb, init, sizeof(init), hipMemcpyHostToDevice, compute_stream));
+            const Box rb = rank_box();
+            PartArgs a;
+            fill_part_args((int)p, 0, rb, a);
+            dim3 grid((unsigned)ceil_div(rb.hi[2] - rb.lo[2], 64), (unsigned)ceil_div(rb.hi[1] - rb.lo[1], 4),
+                      (unsigned)(rb.hi[0] - rb.lo[0]));
+            pi.cond_bb(a, grid, dbb, compute_stream);
+            YKH_HIP(hipGetLastError());
+            int out[8];
+            YKH_HIP(hipMemcpyAsync(out, dbb, sizeof(out), hipMemcpyDeviceToHost, compute_stream));
+            YKH_HIP(hipStreamSynchronize(compute_stream));
+            unsigned long long count;
+            std::memcpy(&count, &out[6], sizeof(count));      // 64-bit counter in out[6..7]
+            Box bb = rb;
+            if (count == 0) { for (int d = 0; d < MAX_DOMAIN_DIMS; d++) bb.hi[d] = bb.lo[d]; }      // never true here
+            else for (int d = 0; d < 3 && d < MAX_DOMAIN_DIMS; d++) { bb.lo[d] = out[d]; bb.hi[d] = out[3 + d] + 1; }
+            part_bb[p] = bb;
+            part_has_bb[p] = 1;
+            unsigned long long vol = 1;
+            for (int d = 0; d < MAX_DOMAIN_DIMS; d++) vol *= (unsigned long long)std::max<idx_t>(0, bb.hi[d] - bb.lo[d]);
+            part_bb_solid[p] = (count == vol);     // the condition holds at every point of the box
+        }
+        if (dbb) YKH_HIP(hipFree(dbb));
+    }
     // kernel variants
     for (size_t p = 0; p < impl.parts.size(); p++) {
         const PartImpl& pi = impl.parts[p];
@@ -440,12 +477,14 @@ void Solution::prepare() {
                 }
             }
         }
+        if (part_needs_predicate((int)p)) v = 0;
         part_variant[p] = v;
         part_xchunk[p] = xchunk_override;
     }
     stats = Stats();
     prepared = true;
     if (auto_tune) run_auto_tuner_now();
+    else if (impl.select_by_timing && variant_override.empty() && !force_scalar) tune_variants(true);
     for (auto& h : after_prepare) h(*this);
 }
 
@@ -506,7 +545,17 @@ void Solution::fill_part_args(int part, idx_t t, const Box& box, PartArgs& a) co
     a.t = t;
 }
 
-void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t, const Box& box, hipStream_t s) {
+void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t, const Box& box_in, hipStream_t s) {
+    // sub-domain parts run inside the bounding box of their condition only; where the condition does not hold
+    // everywhere in that box, only the point kernel (which evaluates it per point) is legal
+    Box box = box_in;
+    if ((size_t)part < part_has_bb.size() && part_has_bb[part]) {
+        for (int d = 0; d < MAX_DOMAIN_DIMS; d++) {
+            box.lo[d] = std::max(box.lo[d], part_bb[part].lo[d]);
+            box.hi[d] = std::min(box.hi[d], part_bb[part].hi[d]);
+        }
+    }
+    if (part_needs_predicate(part)) variant = 0;
     if (box.empty()) return;
     const KernelVariant& kv = impl.parts[part].variants[variant];
     PartArgs a;
@@ -576,12 +625,18 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
     YKH_HIP(hipGetLastError());
 }
 
-void Solution::launch_part(int part, idx_t t, const Box& box, hipStream_t s) {
+void Solution::launch_part(int part, idx_t t, const Box& box_in, hipStream_t s) {
     const PartMeta& pm = *impl.parts[part].meta;
     if (pm.step_cond && !pm.step_cond(t)) return;            // IF_STEP: the part is idle this step
     if (!pm.is_scratch) {
         int v = part_variant[part];
         const KernelVariant& kv = impl.parts[part].variants[v];
+        Box box = box_in;                     // (sub-domain parts: what launch_part_variant will really cover)
+        if ((size_t)part < part_has_bb.size() && part_has_bb[part])
+            for (int d = 0; d < MAX_DOMAIN_DIMS; d++) {
+                box.lo[d] = std::max(box.lo[d], part_bb[part].lo[d]);
+                box.hi[d] = std::min(box.hi[d], part_bb[part].hi[d]);
+            }
         // Thin exterior slabs of a y/z decomposition (8 points wide against a 128 x 32 tile) would keep 1/16 of a
         // marching tile's lanes busy: such boxes go to the point kernel (always variant 0).
         if (thin_slab_point_kernel && kv.star && kv.rx == 0 && ndd == 3 && !box.empty() &&
@@ -593,6 +648,7 @@ void Solution::launch_part(int part, idx_t t, const Box& box, hipStream_t s) {
     // scratch part: evaluate over the box grown by the halo of the scratch var(s) it writes, so that the
     // parts reading them at offsets find every value (the reference does this per micro-block,
     // src/kernel/lib/stencil_calc.cpp:40-289; here the scratch var is a whole device array)
+    const Box& box = box_in;
     Box b = box;
     for (int w = 0; w < pm.n_writes; w++) {
         const AccessGroup& ag = pm.groups[pm.writes[w]];
@@ -719,7 +775,11 @@ Stats Solution::get_stats() {
 // scratch copies of the written step slots so that solution data is left untouched.
 void Solution::reset_auto_tuner(bool enable) { auto_tune = enable; }
 
-void Solution::run_auto_tuner_now() {
+void Solution::run_auto_tuner_now() { tune_variants(false); }
+
+// quick: one pass with the default x-chunking, 1 warm-up + 3 timed launches per shape (used by prepare_solution() for
+// stencil libraries built by the generic registry, whose per-part defaults are a static guess).
+void Solution::tune_variants(bool quick) {
     if (!prepared) YKH_THROW("run_auto_tuner_now() called without calling prepare_solution() first");
     hipEvent_t e0, e1;
     YKH_HIP(hipEventCreate(&e0));
@@ -738,11 +798,12 @@ void Solution::run_auto_tuner_now() {
         int best_v = part_variant[p];
         idx_t best_xc = part_xchunk[p];
         for (size_t k = 0; k < pi.variants.size(); k++) {
-            if (!pi.variants[k].star && pi.variants.size() > 1 && !force_scalar) continue;   // naive only as last resort
+            if (part_needs_predicate((int)p) && k > 0) break;                                  // only the point kernel is legal
+            if (force_scalar && k > 0) break;
             if (std::strncmp(pi.variants[k].name, "abl", 3) == 0) continue;                   // profiling ablations
             if (variant_scratch_bytes(pi.variants[k]) > 0) continue;                          // spilled registers
             std::vector<idx_t> chunks = {0};
-            if (pi.variants[k].star) { chunks.push_back(rb.hi[0] - rb.lo[0]); chunks.push_back(256); chunks.push_back(128); }
+            if (pi.variants[k].star && pi.variants[k].rx == 0 && !quick) { chunks.push_back(rb.hi[0] - rb.lo[0]); chunks.push_back(256); chunks.push_back(128); }
             for (idx_t xc : chunks) {
                 launch_part_variant((int)p, (int)k, xc, 0, rb, compute_stream);   // warm-up
                 YKH_HIP(hipEventRecord(e0, compute_stream));
@@ -754,7 +815,7 @@ void Solution::run_auto_tuner_now() {
                     YKH_HIP(hipEventRecord(e1, compute_stream));
                     YKH_HIP(hipEventSynchronize(e1));
                     YKH_HIP(hipEventElapsedTime(&ms, e0, e1));
-                } while (ms * 1e-3 < auto_tune_trial_secs && reps < 50);
+                } while (quick ? reps < 3 : (ms * 1e-3 < auto_tune_trial_secs && reps < 50));
                 double per = ms / reps;
                 if (env->trace) fprintf(stderr, "auto-tuner: part %s variant %s xchunk %lld: %.4f ms\n", pi.meta->name,
                                         pi.variants[k].name, (long long)xc, per);

@@ -152,7 +152,11 @@ template <class V, typename T> __device__ __forceinline__ V ldv(const T* p) { re
 // accesses would become flat_load/flat_store)
 #define YKH_GLOBAL __attribute__((address_space(1)))
 template <typename T> __device__ __forceinline__ YKH_GLOBAL T* sbase(T* p) {
-    YKH_GLOBAL T* g = (YKH_GLOBAL T*)p;
+    // readfirstlane is free when hipcc already holds the (uniform) value in SGPRs and rescues the cases where it
+    // chose to compute the plane offset with vector instructions ("illegal VGPR to SGPR copy" otherwise)
+    unsigned long long v = (unsigned long long)p;
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    YKH_GLOBAL T* g = (YKH_GLOBAL T*)(((unsigned long long)hi << 32) | lo);
     asm volatile("" : "+s"(g));
     return g;
 }

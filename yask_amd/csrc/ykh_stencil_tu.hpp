@@ -37,6 +37,11 @@ KernelVariant naive_variant() {
     return kv;
 }
 
+template <class P>
+void launch_cond_bb(const PartArgs& a, dim3 grid, int* dev_out, hipStream_t s) {
+    hipLaunchKernelGGL((cond_bb_kernel<P>), grid, dim3(256), 0, s, a, dev_out);
+}
+
 // ABL != 0 variants compute WRONG results on purpose (profiling ablations); their names start with
 // "abl" and neither the default selection nor the auto-tuner ever picks them.
 template <class P, int TZL, int TYL, int RY, int ROT, int ABL = 0>

@@ -371,6 +371,13 @@ class yk_solution:
     def get_kernel_variant_scratch_bytes(self, part, i):
         return self._lib.call("yk_solution_get_kernel_variant_scratch_bytes", self._h, int(part), int(i))
 
+    def get_part_bounding_box(self, part):
+        """(kind, first, last): kind 0 = unconditional part, 1 = box of its IF_DOMAIN condition in this rank
+        (rank-local indices, last inclusive), 2 = the condition holds nowhere in this rank."""
+        first, last = (idx_t * 3)(), (idx_t * 3)()
+        kind = self._lib.call("yk_solution_get_part_bounding_box", self._h, int(part), first, last)
+        return kind, list(first), list(last)
+
     def get_kernel_variant_names(self, part=0):
         n = self._lib.call("yk_solution_get_num_kernel_variants", self._h, part)
         return [self._lib.call("yk_solution_get_kernel_variant_name", self._h, part, i).decode() for i in range(n)]
