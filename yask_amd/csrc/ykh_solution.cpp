@@ -785,7 +785,19 @@ void Solution::tune_variants(bool quick) {
     YKH_HIP(hipEventCreate(&e0));
     YKH_HIP(hipEventCreate(&e1));
     const Box rb = rank_box();
-    // save every var (tuning runs real kernels, which update written vars in place)
+    // save every var (tuning runs real kernels, which update written vars in place); when the copies would not
+    // fit the free device memory the current shapes are kept instead (288 GB hold one copy of a big problem, not two)
+    {
+        size_t need = 0, free_b = 0, total_b = 0;
+        for (auto& v : vars)
+            if (v->is_allocated() && v->is_written) need += v->bytes();
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)need > 0.8 * (double)free_b) {
+            if (env->trace) fprintf(stderr, "auto-tuner: skipped, %zu bytes of var copies do not fit %zu free bytes\n", need, free_b);
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            return;
+        }
+    }
     std::vector<void*> saves(vars.size(), nullptr);
     for (size_t i = 0; i < vars.size(); i++)
         if (vars[i]->is_allocated() && vars[i]->is_written) {
