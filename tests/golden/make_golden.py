@@ -53,6 +53,13 @@ GENERIC_CASES = [
     ("ssg2_20x18x24_s2", "ssg2", (20, 18, 24), 2),                # SSGElastic2Stencil.cpp
     ("fsg2_16x14x20_s2", "fsg2", (16, 14, 20), 2),                # FSGElastic2Stencil.cpp: 81 access groups in one part
     ("cube_20x18x24_s3", "cube", (20, 18, 24), 3),                # SimpleStencils.cpp: dense 3-D cube
+    # step conditions that read var values (evaluated by the kernel): even/odd steps x B(0) > B(1); t >= ti_exp()
+    ("test_step_cond_1d_96_s4", "test_step_cond_1d", (96,), 4),
+    # SWE2dStencil.cpp: 2-D shallow water, scratch vars; physical magnitudes so that 4 steps stay finite
+    ("swe2d_40x36_s4", "swe2d", (40, 36), 4,
+     {"u": (0.0, 0.1), "v": (0.0, 0.1), "e": (0.0, 0.01), "h": (1.0, 0.1), "dt": (0.002, 0.0), "dx": (0.05, 0.0), "dy": (0.05, 0.0),
+      "inv_dx": (20.0, 0.0), "inv_dy": (20.0, 0.0), "g": (9.81, 0.0), "coriolis": (10.0, 0.0), "pe_offset": (0.5, 0.0),
+      "ti_exp": (2.0, 0.0)}),
 ]
 GENERIC_INIT = (1.5, 0.5)
 
@@ -83,7 +90,8 @@ def main():
         index[name] = {"stencil": key, "size": list(size), "steps": steps, "arch": arch,
                        "arrays": sorted(arrays), "init": O.DEFAULT_INIT[key]}
         print("wrote", name, {k: v.shape for k, v in arrays.items()})
-    for name, stencil, size, steps in GENERIC_CASES:
+    for name, stencil, size, steps, *rest in GENERIC_CASES:
+        init_vars = rest[0] if rest else {}
         exe = REF / f"ref_driver.{stencil}.{arch}.exe"
         if not exe.exists():
             print("skip (not built):", exe)
@@ -91,13 +99,14 @@ def main():
         with tempfile.TemporaryDirectory() as td:
             cmd = [str(exe), "-g", *map(str, size), "-steps", str(steps), "-out", f"{td}/o"]
             for v in generic_var_names(stencil):
-                cmd += ["-init", f"{v}:{GENERIC_INIT[0]}:{GENERIC_INIT[1]}"]
+                off, sc = init_vars.get(v, GENERIC_INIT)
+                cmd += ["-init", f"{v}:{off}:{sc}"]
             subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             dump = O.load_ref_dump(f"{td}/o")
         arrays = {f"{n}@{t}": a for (n, t), a in dump.items()}
         np.savez_compressed(HERE / f"{name}.npz", **arrays)
         index[name] = {"stencil": stencil, "size": list(size), "steps": steps, "arch": arch, "arrays": sorted(arrays),
-                       "generic": True, "init": list(GENERIC_INIT)}
+                       "generic": True, "init": list(GENERIC_INIT), "init_vars": {k: list(v) for k, v in init_vars.items()}}
         print("wrote", name, {k: v.shape for k, v in arrays.items()})
     json.dump(index, open(HERE / "index.json", "w"), indent=1, sort_keys=True)
 

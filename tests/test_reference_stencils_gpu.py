@@ -44,9 +44,11 @@ def test_reference_test_stencil_matches_reference(gpu, name):
     soln = fac.new_solution(fac.new_env())
     soln.set_overall_domain_size_vec(meta["size"])
     soln.prepare_solution()
-    off, sc = meta["init"]
-    for i, v in enumerate(soln.get_vars()):
-        v.set_elements_hash(off, sc, hash_id=i)
+    def init(sol):
+        for i, v in enumerate(sol.get_vars()):
+            off, sc = meta.get("init_vars", {}).get(v.get_name(), meta["init"])
+            v.set_elements_hash(off, sc, hash_id=i)
+    init(soln)
     soln.run_solution(0, meta["steps"] - 1)
     checked = 0
     for key in meta["arrays"]:
@@ -69,8 +71,7 @@ def test_reference_test_stencil_matches_reference(gpu, name):
             s2.set_overall_domain_size_vec(meta["size"])
             s2.apply_command_line_options(f"-hip_variant {vn}")
             s2.prepare_solution()
-            for i, v in enumerate(s2.get_vars()):
-                v.set_elements_hash(off, sc, hash_id=i)
+            init(s2)
             s2.run_solution(0, meta["steps"] - 1)
             for key in meta["arrays"]:
                 vname, t = key.split("@")

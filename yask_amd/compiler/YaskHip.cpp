@@ -186,9 +186,10 @@ namespace yask {
         public:
             const DimCtx& dc;
             bool step_only;          // IF_STEP: only the step index may appear
+            HipEmitter* em;          // non-null: IF_STEP evaluated on the device, may read vars without domain dims
             bool failed = false;
             string fail_why;
-            CondEmitter(const DimCtx& d, bool so) : dc(d), step_only(so) {}
+            CondEmitter(const DimCtx& d, bool so, HipEmitter* e = 0) : dc(d), step_only(so), em(e) {}
             string fail(const string& why) { failed = true; if (fail_why.empty()) fail_why = why; return "0"; }
             string visit(ConstExpr* ce) override {
                 double v = ce->get_num_val();
@@ -198,7 +199,7 @@ namespace yask {
             string visit(CodeExpr*) override { return fail("hand-written code expression in a condition"); }
             string visit(IndexExpr* ie) override {
                 auto type = ie->get_type();
-                if (type == STEP_INDEX) return step_only ? "t" : "a.sstep()";
+                if (type == STEP_INDEX) return (step_only && !em) ? "t" : "a.sstep()";
                 if (step_only) return fail("non-step index in a step condition");
                 string d = to_string(dc.domain_idx(ie->_get_name()));
                 if (type == DOMAIN_INDEX) return "a.template sidx<" + d + ">()";
@@ -206,7 +207,19 @@ namespace yask {
                 if (type == LAST_INDEX) return "a.template last_idx<" + d + ">()";
                 return fail("misc index in a condition");
             }
-            string visit(VarPoint*) override { return fail("var value in a condition"); }
+            string visit(VarPoint* vp) override {
+                // Values of vars without step and domain dims (scalars, misc-dim tables at constant indices) may
+                // steer a step condition; the kernel then evaluates it (the reference reads them on the host,
+                // YaskKernel.cpp "is_in_valid_step").
+                if (!em || !step_only) return fail("var value in a condition");
+                Group g; int o[3];
+                if (!point_info(dc, vp, g, o) || g.has_step) return fail("var with a step index in a condition");
+                for (auto& dim : g.var->get_dims())
+                    if (dim->get_type() == DOMAIN_INDEX) return fail("var over domain dims in a condition");
+                int gi = em->group_of(g);
+                em->note_read(gi, o);
+                return "(double)a.template rd<" + to_string(gi) + ", 0, 0, 0>()";
+            }
             string visit(UnaryNumExpr* ue) override { return "(" + ue->get_op_str() + ue->_get_rhs()->accept(this) + ")"; }
             string visit(UnaryNum2BoolExpr* ue) override { return "(" + ue->get_op_str() + ue->_get_rhs()->accept(this) + ")"; }
             string visit(UnaryBoolExpr* ue) override { return "(" + ue->get_op_str() + ue->_get_rhs()->accept(this) + ")"; }
@@ -426,9 +439,17 @@ namespace yask {
                         THROW_YASK_EXCEPTION("the 'cdna4_hip' target cannot render the sub-domain condition of part '" + pname +
                                              "' of solution '" + sname + "': " + ce.fail_why);
                 }
+                bool step_cond_dev = false;          // evaluated by the kernel (reads var values)
+                string step_cond_dev_code = "true";
                 if (has_step_cond) {
                     CondEmitter ce(dc, true);
                     step_cond_code = part->step_cond->accept(&ce);
+                    if (ce.failed && ce.fail_why == "var value in a condition") {
+                        CondEmitter cd(dc, true, &em);
+                        step_cond_dev_code = part->step_cond->accept(&cd);
+                        if (!cd.failed) { ce.failed = false; step_cond_dev = true; step_cond_code = "true"; }
+                        else ce.fail_why = cd.fail_why;
+                    }
                     if (ce.failed)
                         THROW_YASK_EXCEPTION("the 'cdna4_hip' target cannot render the step condition of part '" + pname +
                                              "' of solution '" + sname + "': " + ce.fail_why);
@@ -530,7 +551,10 @@ namespace yask {
                       "    static constexpr bool has_domain_cond = " << (has_cond ? "true" : "false") << ";\n"
                       "    template <class A>\n    __device__ __forceinline__ static bool cond(const A& a) { return " << cond_code << "; }\n"
                       "    static constexpr bool has_step_cond = " << (has_step_cond ? "true" : "false") << ";\n"
-                      "    static bool step_cond(long long t) { return " << step_cond_code << "; }\n";
+                      "    static bool step_cond(long long t) { return " << step_cond_code << "; }\n"
+                      "    // step condition that reads var values: evaluated per launch by the point kernel\n"
+                      "    static constexpr bool has_step_cond_dev = " << (step_cond_dev ? "true" : "false") << ";\n"
+                      "    template <class A>\n    __device__ __forceinline__ static bool step_cond_dev(const A& a) { return " << step_cond_dev_code << "; }\n";
                 os << "};\n\n";
 
                 ostringstream pm;
@@ -538,7 +562,8 @@ namespace yask {
                    << pname << "::reads, " << pname << "::n_writes, " << pname << "::writes,\n     " << stats.get_num_ops() << ", "
                    << stats.get_num_reads() << ", " << stats.get_num_writes() << ", " << stage_no << ", "
                    << (has_cond ? "true" : "false") << ", " << (has_step_cond ? "true" : "false") << ", "
-                   << (part->is_scratch() ? "true" : "false") << ", &" << pname << "::step_cond},\n";
+                   << (part->is_scratch() ? "true" : "false") << ", &" << pname << "::step_cond, "
+                   << (step_cond_dev ? "true" : "false") << "},\n";
                 part_idx[pname] = (int)part_names.size();
                 members.push_back((int)part_names.size());
                 part_names.push_back(pname);

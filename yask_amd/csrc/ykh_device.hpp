@@ -166,6 +166,9 @@ __global__ void __launch_bounds__(256) naive_kernel(const PartArgs a) {
     int x = a.x0 + blockIdx.z;
     if (z >= a.z1 || y >= a.y1 || x >= a.x1) return;
     NaiveAcc<P> acc{a, x, y, z};
+    if constexpr (P::has_step_cond_dev) {
+        if (!P::step_cond_dev(acc)) return;      // IF_STEP on var values (uniform over the launch)
+    }
     if constexpr (P::has_domain_cond) {
         if (!P::cond(acc)) return;      // sub-domain parts: the predicate replaces the reference's BB lists
     }

@@ -71,6 +71,7 @@ struct PartMeta {
     bool has_step_cond;
     bool is_scratch = false;                       // writes scratch vars: evaluated over the box grown by their halos
     bool (*step_cond)(long long t) = nullptr;      // IF_STEP predicate (host); null = always
+    bool has_step_cond_dev = false;                // IF_STEP predicate that reads var values: evaluated by the point kernel
 };
 
 struct StageMeta {

@@ -280,6 +280,7 @@ public:
     std::vector<char> part_has_bb, part_bb_solid;    // solid: the condition holds everywhere in the box
     bool part_needs_predicate(int part) const {      // only the point kernel evaluates the condition per point
         const PartMeta& pm = *impl.parts[part].meta;
+        if (pm.has_step_cond_dev) return true;
         if (!pm.has_domain_cond) return false;
         return !((size_t)part < part_has_bb.size() && part_has_bb[part] && part_bb_solid[part]);
     }
