@@ -107,7 +107,10 @@ def _single(stencil, g, steps, opts):
                                      ((2, 1, 1), "-min_exterior 12 -hip_variant star25d_z128_y16_r1_u")])
 def test_iso3dfd_two_ranks_equal_one_rank(gpu, nr, opts):
     g, steps = (48, 40, 72), 4
-    # bit-exactness needs one kernel everywhere: keep thin y/z exterior slabs on the marching kernel here
+    # bit-exactness needs one kernel everywhere: name it (on grids this small prepare_solution() otherwise times the
+    # shapes and each rank keeps its own winner) and keep thin y/z exterior slabs on the marching kernel
+    if "-hip_variant" not in opts:
+        opts += " -hip_variant starlin_v4_z128_y16_r1_m_nt_w2_c4"
     opts = (opts + " -no-hip_thin_slab_point_kernel").strip()
     two = _two_ranks("iso3dfd", g, steps, opts, nr)
     one = _single("iso3dfd", g, steps, opts)
@@ -120,8 +123,9 @@ def test_ssg_two_ranks_equal_one_rank(gpu):
     """9 in-place fields, 2 stages with an exchange after each, asymmetric halos (3/4), `mu` read
     diagonally (L1 norm 2 -> edge neighbours, here none with 2 ranks, but the boundary extension applies)."""
     g, steps = (40, 24, 36), 3
-    two = _two_ranks("ssg", g, steps, "", (2, 1, 1))
-    one = _single("ssg", g, steps, "")
+    opts = "-hip_variant march_v2_z128_y8_w2"        # one kernel everywhere (see above)
+    two = _two_ranks("ssg", g, steps, opts, (2, 1, 1))
+    one = _single("ssg", g, steps, opts)
     ref = O.run_ssg(g, steps)
     for n in O.SSG_FIELDS:
         assert np.array_equal(two[n], one[n]), n

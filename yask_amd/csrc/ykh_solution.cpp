@@ -425,6 +425,7 @@ void Solution::prepare() {
         if (dbb) YKH_HIP(hipFree(dbb));
     }
     // kernel variants
+    bool small_grid = false;
     for (size_t p = 0; p < impl.parts.size(); p++) {
         const PartImpl& pi = impl.parts[p];
         int v = pi.default_variant;
@@ -454,6 +455,7 @@ void Solution::prepare() {
             };
             const idx_t cus = std::max(1, env->num_cus);
             if (blocks_of(pi.variants[v]) < cus) {
+                small_grid = true;       // ... and the shapes are timed below; this score is the fallback
                 const std::string dn = pi.variants[v].name;
                 const std::string family = dn.substr(0, dn.find("_z"));
                 // score = share of the CUs that get a workgroup x share of a tile's lanes that do useful work
@@ -484,7 +486,9 @@ void Solution::prepare() {
     stats = Stats();
     prepared = true;
     if (auto_tune) run_auto_tuner_now();
-    else if (impl.select_by_timing && variant_override.empty() && !force_scalar) tune_variants(true);
+    // Grids too small to give every CU a default tile: which family wins depends on the size (iso3dfd 64^3: point
+    // kernel 39 Gpoints/s vs 6.5 for the default marching shape; 256^3: star25d 290 vs 209), so time them once.
+    else if ((impl.select_by_timing || small_grid) && variant_override.empty() && !force_scalar) tune_variants(true);
     for (auto& h : after_prepare) h(*this);
 }
 
