@@ -134,15 +134,20 @@ struct NaiveAcc {
     typedef T V;
     const PartArgs& a;
     int x, y, z;
+    idx_t c;          // x*sx + y*sy + z: the point's offset in every var over all domain dims (shared strides)
+    // Vars over all domain dims share strides and pads: their accesses are (uniform base + uniform offset) + c, so a
+    // part with 40 access groups does not need 120 strides in SGPRs (awp: they spilled, and so did the kernel).
     template <int G, int DX, int DY, int DZ>
     __device__ __forceinline__ V rd() const {
         const T* p = (const T*)a.ptr[G];
-        return p[(idx_t)(x + DX) * a.gsx[G] + (idx_t)(y + DY) * a.gsy[G] + (idx_t)(z + DZ) * a.gsz[G]];
+        if constexpr (P::group_full[G]) return (p + ((idx_t)DX * a.sx + (idx_t)DY * a.sy + DZ))[c];
+        else return p[(idx_t)(x + DX) * a.gsx[G] + (idx_t)(y + DY) * a.gsy[G] + (idx_t)(z + DZ) * a.gsz[G]];
     }
     template <int G>
     __device__ __forceinline__ void wr(V v) const {
         T* p = (T*)a.ptr[G];
-        p[(idx_t)x * a.gsx[G] + (idx_t)y * a.gsy[G] + (idx_t)z * a.gsz[G]] = v;
+        if constexpr (P::group_full[G]) p[c] = v;
+        else p[(idx_t)x * a.gsx[G] + (idx_t)y * a.gsy[G] + (idx_t)z * a.gsz[G]] = v;
     }
     __device__ __forceinline__ void pin(V&) const {}   // scheduling hint of the generated code (see MarchAcc)
     // global index of the point in domain dim D / the evaluation step, as values
@@ -165,7 +170,7 @@ __global__ void __launch_bounds__(256) naive_kernel(const PartArgs a) {
     int y = a.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     int x = a.x0 + blockIdx.z;
     if (z >= a.z1 || y >= a.y1 || x >= a.x1) return;
-    NaiveAcc<P> acc{a, x, y, z};
+    NaiveAcc<P> acc{a, x, y, z, (idx_t)x * a.sx + (idx_t)y * a.sy + z};
     if constexpr (P::has_step_cond_dev) {
         if (!P::step_cond_dev(acc)) return;      // IF_STEP on var values (uniform over the launch)
     }
@@ -190,7 +195,7 @@ __global__ void __launch_bounds__(256) cond_bb_kernel(const PartArgs a, int* out
     bool on = false;
     if constexpr (P::has_domain_cond) {
         if (z < a.z1 && y < a.y1 && x < a.x1) {
-            NaiveAcc<P> acc{a, x, y, z};
+            NaiveAcc<P> acc{a, x, y, z, 0};
             on = P::cond(acc);
         }
     }

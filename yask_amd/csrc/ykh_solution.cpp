@@ -346,14 +346,16 @@ void Solution::setup_rank() {
 void Solution::prepare() {
     for (auto& h : before_prepare) h(*this);
     setup_rank();
-    // solution-wide pads = max halo over all vars (see Var::compute_geometry)
+    // solution-wide pads = max halo over all vars, scratch vars included (see Var::compute_geometry): every var
+    // over all domain dims then has the same strides, which the kernels rely on (P::group_full)
     for (int d = 0; d < ndd; d++) {
         shared_pad_l_[d] = shared_pad_r_[d] = 0;
-        for (auto& v : vars) {
-            if (v->fixed_size || !v->uses_domain[d]) continue;
-            shared_pad_l_[d] = std::max({shared_pad_l_[d], v->halo_l[d], v->min_pad_l[d]});
-            shared_pad_r_[d] = std::max({shared_pad_r_[d], v->halo_r[d], v->min_pad_r[d]});
-        }
+        for (auto* list : {&vars, &scratch_vars})
+            for (auto& v : *list) {
+                if (v->fixed_size || !v->uses_domain[d]) continue;
+                shared_pad_l_[d] = std::max({shared_pad_l_[d], v->halo_l[d], v->min_pad_l[d]});
+                shared_pad_r_[d] = std::max({shared_pad_r_[d], v->halo_r[d], v->min_pad_r[d]});
+            }
     }
     for (int d = 0; d < ndd; d++) {
         idx_t need = std::max(shared_pad_l_[d], shared_pad_r_[d]);
@@ -531,7 +533,7 @@ void Solution::fill_part_args(int part, idx_t t, const Box& box, PartArgs& a) co
         for (int d = 0; d < ndd; d++) is_full &= v->uses_domain[d];
         if (is_full && !v->fixed_size && !full) full = v;
     }
-    if (ndd == 3 && full) {
+    if (full) {      // (solutions with fewer than 3 domain dims: missing dims have stride 0 and extent 1)
         a.sx = full->stride[0];
         a.sy = full->stride[1];
         a.ax0 = (int)-full->pad_l[0]; a.ax1 = (int)(full->dom_size[0] + full->pad_r[0]);

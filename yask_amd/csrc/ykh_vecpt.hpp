@@ -26,19 +26,25 @@ struct VecPtAcc {
     typedef typename vecn<T, VZ>::type V;
     const PartArgs& a;
     int x, y, z0;      // z0: first of the VZ points, multiple of VZ
+    idx_t c;           // x*sx + y*sy + z0: offset of the point in every var over all domain dims (shared strides)
     template <int G, int DX, int DY, int DZ>
     __device__ __forceinline__ V rd() const {
-        const T* p = (const T*)a.ptr[G] + (idx_t)(x + DX) * a.gsx[G] + (idx_t)(y + DY) * a.gsy[G];
-        if (a.gsz[G] == 0) return V(p[0]);                     // var without the unit-stride dim: broadcast
         constexpr int q = (DZ >= 0) ? DZ / VZ : -((-DZ + VZ - 1) / VZ);   // floor(DZ / VZ)
         constexpr int e = DZ - q * VZ;                                    // 0 .. VZ-1
-        const T* pz = p + z0 + q * VZ;
+        const T* pz;
+        if constexpr (P::group_full[G])      // uniform base + uniform offset, + c (no per-group strides in SGPRs)
+            pz = ((const T*)a.ptr[G] + ((idx_t)DX * a.sx + (idx_t)DY * a.sy + q * VZ)) + c;
+        else {
+            const T* p = (const T*)a.ptr[G] + (idx_t)(x + DX) * a.gsx[G] + (idx_t)(y + DY) * a.gsy[G];
+            if (a.gsz[G] == 0) return V(p[0]);                 // var without the unit-stride dim: broadcast
+            pz = p + z0 + q * VZ;
+        }
         if constexpr (e == 0) return ldv<V>(pz);
         else return zshiftn<T, VZ, e>(ldv<V>(pz), ldv<V>(pz + VZ));
     }
     template <int G>
     __device__ __forceinline__ void wr(V v) const {
-        T* p = (T*)a.ptr[G] + (idx_t)x * a.gsx[G] + (idx_t)y * a.gsy[G] + z0;
+        T* p = P::group_full[G] ? (T*)a.ptr[G] + c : (T*)a.ptr[G] + (idx_t)x * a.gsx[G] + (idx_t)y * a.gsy[G] + z0;
         if (z0 >= a.z0 && z0 + VZ <= a.z1) stv<V>(p, v);
         else
             static_for<VZ>([&](auto ec) {
@@ -81,7 +87,7 @@ __global__ void __launch_bounds__(TZL* TYL) vecpt_kernel(const PartArgs a) {
     static_for<RX>([&](auto rc) {
         const int x = xs + decltype(rc)::value;
         if (x < a.x1) {
-            VecPtAcc<P, VZ> acc{a, x, y, z0};
+            VecPtAcc<P, VZ> acc{a, x, y, z0, (idx_t)x * a.sx + (idx_t)y * a.sy + z0};
             P::eval(acc);
         }
     });
