@@ -299,6 +299,10 @@ std::string Solution::get_command_line_help() const {
           " -auto_tune_trial_secs <s>\n"
           " -[no-]force_scalar    use the generic one-thread-per-point kernel\n"
           " -hip_variant <name>   force a kernel variant     -hip_xchunk <n>  x-march chunk length\n"
+          " -[no-]hip_round_launches          more tiles than CUs: one launch per CU-filling round of tile rows (default on)\n"
+          " -[no-]hip_direct_halo             x-face halos of full-dim vars are sent/received in place (default on)\n"
+          " -[no-]hip_thin_slab_point_kernel  thin y/z exterior slabs run on the point kernel (default on)\n"
+          " -hip_overlap_splits <n>           interior launches per step when halos are overlapped (default 4)\n"
           " CPU-only options (-Mb -mb -nb -pb -max_threads -outer_threads -inner_threads -numa_pref\n"
           "  -bind_inner_threads -bundle_allocs -use_shm -use_device_mpi ...) are accepted and ignored.\n";
     return os.str();
