@@ -13,5 +13,8 @@ void ssg_variants_k4(PartImpl& p) {
     p.variants.push_back(march_variant<part_2, 4, 64, 8, 2, 1, false, 1, 1>());   // + non-temporal one-touch streams
     p.variants.push_back(march_variant<part_2, 4, 32, 16, 2, 1, false, 1, 1>());
     p.variants.push_back(march_variant<part_2, 2, 64, 8, 2, 1, false, 2, 1>());
+    p.variants.push_back(march_variant<part_2, 4, 16, 32, 2, 1, false, 1, 1>());   // tile 64x32: less y halo, more z halo
+    p.variants.push_back(march_variant<part_2, 2, 64, 8, 2, 2, false, 1, 1>());    // 8-byte lanes, two rows per thread, nt
+    p.variants.push_back(march_variant<part_2, 2, 32, 16, 2, 2, false, 1, 1>());   // tile 64x32 with 8-byte lanes
 }
 }  // namespace ykh
