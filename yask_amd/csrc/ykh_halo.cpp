@@ -116,7 +116,7 @@ static size_t move_slabs(Solution& s, const std::vector<Slab>& slabs, void* buf,
 void Solution::exchange_halos(idx_t /*t_written*/, int /*stage*/, bool start_only, bool finish_only) {
     if (env->nranks <= 1 || xfers.empty()) return;
     if (!env->exch_start) YKH_THROW("multi-rank solution has no halo-exchange transport installed in its env");
-    static thread_local std::vector<HaloMsg> msgs;
+    std::vector<HaloMsg>& msgs = pending_msgs;      // messages between a start and the matching finish
     if (!finish_only) {
         bool any = false;
         for (auto& v : vars)

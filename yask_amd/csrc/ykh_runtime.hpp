@@ -275,6 +275,7 @@ public:
     std::vector<std::shared_ptr<Var>> vars;
     std::map<std::string, std::shared_ptr<Var>> var_map;
     std::vector<std::shared_ptr<Var>> scratch_vars;   // compiler-declared scratch vars: device arrays, not in the API
+    std::vector<HaloMsg> pending_msgs;               // halo messages in flight (exchange_halos start -> finish)
     std::vector<int> part_variant;                   // chosen variant per part
     std::vector<Box> part_bb;                        // sub-domain parts: bounding box of the condition (local indices)
     std::vector<char> part_has_bb, part_bb_solid;    // solid: the condition holds everywhere in the box

@@ -791,9 +791,19 @@ void Solution::run_auto_tuner_now() { tune_variants(false); }
 // stencil libraries built by the generic registry, whose per-part defaults are a static guess).
 void Solution::tune_variants(bool quick) {
     if (!prepared) YKH_THROW("run_auto_tuner_now() called without calling prepare_solution() first");
-    hipEvent_t e0, e1;
-    YKH_HIP(hipEventCreate(&e0));
-    YKH_HIP(hipEventCreate(&e1));
+    // events and var copies are released on every exit path (a failing launch throws)
+    struct Scratch {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        std::vector<void*> saves;
+        ~Scratch() {
+            for (auto p : saves) if (p) (void)hipFree(p);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } sc;
+    YKH_HIP(hipEventCreate(&sc.e0));
+    YKH_HIP(hipEventCreate(&sc.e1));
+    hipEvent_t e0 = sc.e0, e1 = sc.e1;
     const Box rb = rank_box();
     // save every var (tuning runs real kernels, which update written vars in place); when the copies would not
     // fit the free device memory the current shapes are kept instead (288 GB hold one copy of a big problem, not two)
@@ -803,12 +813,11 @@ void Solution::tune_variants(bool quick) {
             if (v->is_allocated() && v->is_written) need += v->bytes();
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)need > 0.8 * (double)free_b) {
             if (env->trace) fprintf(stderr, "auto-tuner: skipped, %zu bytes of var copies do not fit %zu free bytes\n", need, free_b);
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
             return;
         }
     }
-    std::vector<void*> saves(vars.size(), nullptr);
+    std::vector<void*>& saves = sc.saves;
+    saves.assign(vars.size(), nullptr);
     for (size_t i = 0; i < vars.size(); i++)
         if (vars[i]->is_allocated() && vars[i]->is_written) {
             YKH_HIP(hipMalloc(&saves[i], vars[i]->bytes()));
@@ -854,9 +863,6 @@ void Solution::tune_variants(bool quick) {
             YKH_HIP(hipMemcpyAsync(vars[i]->dptr, saves[i], vars[i]->bytes(), hipMemcpyDeviceToDevice, compute_stream));
         }
     YKH_HIP(hipStreamSynchronize(compute_stream));
-    for (auto s : saves) if (s) (void)hipFree(s);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
 }
 
 idx_t Solution::compare_data(const Solution& ref, double eps) const {
