@@ -135,6 +135,11 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     stencil, descr, dflt_n, dtype, BYTES_PER_POINT, init = WORKLOADS[args.workload]
+    if local_rank == 0:
+        from yask_amd import _capi
+        _capi.ensure_built((stencil,))     # no-op when the kernel library is already built in-tree
+    if world > 1:
+        torch.distributed.barrier()
     fac = yk_factory(stencil)
     env, transport = ydist.new_env(fac, args.transport)
     soln = fac.new_solution(env)

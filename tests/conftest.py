@@ -26,4 +26,7 @@ def _have_gpu():
 def gpu():
     if not _have_gpu():
         pytest.fail("GPU test selected but no GPU is visible (these tests never fall back to the CPU)")
+    # a box that received the sources only: compile the HIP kernel libraries in-tree first (no-op when they are there)
+    from yask_amd import _capi
+    _capi.ensure_built(("iso3dfd", "3axis", "3axis_r1", "ssg", "test_3d", "awp_abc", "swe2d"))
     return True

@@ -203,6 +203,25 @@ def lib_path(stencil: str) -> Path:
 _loaded: dict[str, C.CDLL] = {}
 
 
+def ensure_built(stencils=("iso3dfd",)) -> None:
+    """Entry points that may start on a box holding only the sources (tests' `gpu` fixture, smoke(), bench.py) call
+    this first: if a kernel library is missing it is compiled in-tree with hipcc (minutes), exactly as
+    __graft_entry__.build() does.  This builds the HIP library -- it is not a fallback around it; load() stays strict."""
+    import shutil
+    import subprocess
+    import sys
+    missing = [s for s in stencils if not lib_path(s).exists()]
+    if not missing:
+        return
+    if not shutil.which("hipcc") and not Path("/opt/rocm/bin/hipcc").exists():
+        return                       # load() will raise with the build instructions
+    print(f"yask_amd: building kernel libraries (missing: {', '.join(missing)}) ...", file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env["PATH"] = env.get("PATH", "") + ":/opt/rocm/bin"
+    subprocess.check_call(["make", "-C", str(_PKG / "csrc"), f"-j{min(16, os.cpu_count() or 4)}"], env=env,
+                          stdout=subprocess.DEVNULL)
+
+
 def load(stencil: str) -> C.CDLL:
     """dlopen the stencil's kernel library and attach prototypes. Raises if it is not built."""
     if stencil in _loaded:
