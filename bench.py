@@ -303,7 +303,10 @@ def main():
     else:
         soln.set_rank_domain_size_vec([n, n, n])
         scaling = "weak"
-    rem = soln.apply_command_line_options("-hip_step_timers " + args.opts)
+    # the placement search (a best-of-6 draw of the arrays' physical placement) is the caller's choice since
+    # round 3: one process per GPU asks for it; ranks that share a device (tests) must not race for its memory
+    shared_dev = world > 1 and os.environ.get("YASK_DIST_BACKEND", "") == "gloo"
+    rem = soln.apply_command_line_options(("-hip_step_timers " + ("" if shared_dev else "-hip_placement_trials 6 ")) + args.opts)
     assert rem == "", rem
     soln.prepare_solution()
     for name, (off, sc, hid) in init.items():

@@ -60,7 +60,8 @@ def test_search_reports_what_it_measured_and_changes_no_result(gpu):
 def test_no_search_on_small_solutions_nor_over_existing_data(gpu):
     small = make("iso3dfd", (64, 64, 64))
     assert small.get_placement_trials() is None
-    s = make("iso3dfd", (256, 256, 256))
+    assert make("iso3dfd", (256, 256, 256)).get_placement_trials() is None       # the search is opt-in: default = 1 trial
+    s = make("iso3dfd", (256, 256, 256), "-hip_placement_trials 4")
     assert s.get_placement_trials() is not None
     hash_init(s, "iso3dfd")
     s.run_solution(0, 1)

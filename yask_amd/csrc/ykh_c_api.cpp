@@ -717,23 +717,24 @@ int yk_var_is_storage_layout_identical(yk_var_h v, yk_var_h o) {
     return 1;
     YK_CATCH(0)
 }
-// fuse_vars (yk_var_api.hpp:1395): make `v` hold the data of `source`. Storage here is device memory
-// owned by one var, so the fuse is a device-to-device copy when layouts match (shared ownership of one
-// allocation is not supported on the device path yet).
+// fuse_vars (yk_var_api.hpp:1370-1396, yk_var_apis.cpp:334-367): `v` becomes another reference to `source` -- one
+// allocation, shared by reference count, under two names (possibly in two solutions): what is written through one is read
+// through the other, release_storage() on either applies to both, the storage is freed when the last holder goes.
 int yk_var_fuse_vars(yk_var_h v, yk_var_h src) {
     YK_TRY
     Var *a = V(v), *b = V(src);
-    if (!yk_var_is_storage_layout_identical(v, src)) YKH_THROW("fuse_vars: storage layouts of '" + a->name + "' and '" + b->name + "' differ");
-    if (!b->is_allocated()) { a->release(); return 0; }
-    if (!a->is_allocated()) a->allocate();
+    if (a->dims.size() != b->dims.size()) YKH_THROW("fuse_vars: '" + a->name + "' and '" + b->name + "' have different numbers of dims");
+    for (size_t i = 0; i < a->dims.size(); i++)
+        if (a->dims[i].name != b->dims[i].name) YKH_THROW("fuse_vars: dims of '" + a->name + "' and '" + b->name + "' differ");
+    // (a var used by its solution's kernels must keep the geometry the kernels were given: layouts must agree)
+    if ((b->is_allocated() || a->soln->prepared || b->soln->prepared) && !yk_var_is_storage_layout_identical(v, src))
+        YKH_THROW("fuse_vars: storage layouts of '" + a->name + "' and '" + b->name + "' differ");
     b->before_device_use();
-    // ordered after everything queued on either solution's stream, and complete on return
-    YKH_HIP(hipStreamSynchronize(b->soln->compute_stream));
-    YKH_HIP(hipMemcpyAsync(a->dptr, b->dptr, a->bytes(), hipMemcpyDeviceToDevice, a->soln->compute_stream));
+    // everything queued on either solution's stream so far sees the storage it was queued with
     YKH_HIP(hipStreamSynchronize(a->soln->compute_stream));
-    a->first_valid_step = b->first_valid_step;
-    a->set_dirty_all(true);
-    a->after_device_write();
+    YKH_HIP(hipStreamSynchronize(b->soln->compute_stream));
+    a->fuse_with(*b);
+    a->soln->drop_step_graphs();        // (captured launches hold the old addresses)
     return 0;
     YK_CATCH(1)
 }

@@ -241,30 +241,46 @@ TcpState* tcp_connect_mesh(int rank, int nranks, const char* addr, int base_port
     std::vector<int> ports(nranks, 0);
     ports[rank] = local_port_of(lfd);
     if (ports[rank] <= 0) return fail();
-    // ---- port table through rank 0
+    // ---- port table through rank 0.  Every peer is reached at the ONE address `addr` with its own port, so the mesh only
+    // works when all ranks run on one host: each rank reports its host name with its port, and rank 0 refuses a job that
+    // spans hosts (an all-zero table) instead of letting every connect() run into its time limit.
+    struct Hello { int rank, port; char host[64]; };
+    Hello me{};
+    me.rank = rank; me.port = ports[rank];
+    if (::gethostname(me.host, sizeof(me.host) - 1) != 0) me.host[0] = 0;
     if (rank == 0) {
         rfd = listen_on(base_port);
         if (rfd < 0) { fprintf(stderr, "yask tcp transport: cannot listen on port %d: %s\n", base_port, strerror(errno)); return fail(); }
         gathered.assign(nranks, -1);
+        bool one_host = true;
         for (int k = 1; k < nranks; k++) {
             int fd = accept_within(rfd, 120000);
-            int msg[2] = {-1, -1};
+            Hello h{};
+            h.rank = h.port = -1;
             if (fd < 0) return fail();
-            if (!recv_all(fd, msg, sizeof(msg)) || msg[0] <= 0 || msg[0] >= nranks || gathered[msg[0]] >= 0 || msg[1] <= 0) { ::close(fd); return fail(); }
-            gathered[msg[0]] = fd;
-            ports[msg[0]] = msg[1];
+            if (!recv_all(fd, &h, sizeof(h)) || h.rank <= 0 || h.rank >= nranks || gathered[h.rank] >= 0 || h.port <= 0) { ::close(fd); return fail(); }
+            h.host[sizeof(h.host) - 1] = 0;
+            if (std::strcmp(h.host, me.host) != 0) {
+                fprintf(stderr, "yask tcp transport: rank %d runs on host '%s', rank 0 on '%s' -- this test transport connects all ranks "
+                                "through one address and needs them on one host (use the RCCL transport for multi-node jobs)\n", h.rank, h.host, me.host);
+                one_host = false;
+            }
+            gathered[h.rank] = fd;
+            ports[h.rank] = h.port;
         }
+        if (!one_host) std::fill(ports.begin(), ports.end(), 0);
         for (int k = 1; k < nranks; k++)
             if (!send_all(gathered[k], ports.data(), sizeof(int) * nranks)) return fail();
         for (int& fd : gathered) if (fd >= 0) { ::close(fd); fd = -1; }
         ::close(rfd); rfd = -1;
+        if (!one_host) return fail();
     } else {
         int fd = connect_to(addr, base_port, 120.0);
         if (fd < 0) return fail();
-        int msg[2] = {rank, ports[rank]};
-        const bool ok = send_all(fd, msg, sizeof(msg)) && recv_all(fd, ports.data(), sizeof(int) * nranks);
+        const bool ok = send_all(fd, &me, sizeof(me)) && recv_all(fd, ports.data(), sizeof(int) * nranks);
         ::close(fd);
         if (!ok) return fail();
+        if (ports[0] == 0 && ports[rank] == 0) { fprintf(stderr, "yask tcp transport: rank 0 refused the job (ranks on more than one host)\n"); return fail(); }
     }
     // ---- the mesh itself
     for (int i = 0; i < rank; i++) {
@@ -357,8 +373,11 @@ int yk_env_init_from_launcher(yk_env_h e) {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return 1;
         const int dev = lrank % ndev;
+        // one process per GPU: a launcher-started rank binds to its own GPU (LOCAL_RANK) before the first allocation
         if (hipSetDevice(dev) != hipSuccess) return 1;
         e->env->device = dev;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) e->env->num_cus = prop.multiProcessorCount;
         const char* addr = getenv("MASTER_ADDR");
         if (!addr || !*addr) addr = "127.0.0.1";
         static const char* const port_v[] = {"MASTER_PORT", nullptr};

@@ -241,7 +241,16 @@ public:
     void* dptr = nullptr;        // first byte of the var's storage ...
     void* alloc_ptr = nullptr;   // ... inside this allocation (dptr = alloc_ptr + the var's skew, Var::allocate)
     size_t alloc_bytes = 0;      // size of that allocation (a changed step/misc allocation must re-allocate)
+    // Shared ownership of the allocation (generic_var.hpp:136-140: storage is a shared_ptr): hipFree() runs when the last
+    // var holding it lets go.  fuse_vars() (yk_var_api.hpp:1370-1396) makes this var "another reference to the source var":
+    // the vars of a fuse group share storage, valid-step window and dirty flags, and release() on one applies to all.
+    std::shared_ptr<void> alloc_owner;
+    std::shared_ptr<std::vector<Var*>> fuse_group;      // every var fused with this one, this one included (null: not fused)
+    void fuse_with(Var& src);
+    void adopt_storage(std::shared_ptr<void> owner, void* alloc, void* data, size_t nbytes);   // ... for the whole fuse group
+    static std::shared_ptr<void> own_allocation(void* alloc);                                   // owner whose deleter is hipFree
     bool storage_fits() const { return dptr && alloc_bytes == std::max<size_t>(bytes(), 256); }
+    void drop_storage_refs();    // this var only: forget the storage (freed when no var of the fuse group holds it any more)
     idx_t origin_elems = 0;      // element offset of local (0,0,0), misc first, within a slot
 private:
     void init_dims_from_meta();
@@ -324,7 +333,9 @@ public:
                                    // well (the exchange waits for the slabs only).  Measured on one GPU (profiles/r02r_ext_streams):
                                    // the cross-stream dependencies cost more than the idle CUs of the thin slabs -- exterior of a 512^3
                                    // block 0.19 ms serial, 0.22-0.29 ms side by side; ext + int 0.575 / 0.617 / 0.667 ms for 0 / 1 / 2
-    idx_t placement_trials = 6;    // -hip_placement_trials <n>: sets of var allocations prepare_solution() draws and times (tune_placement())
+    idx_t placement_trials = 1;    // -hip_placement_trials <n>: sets of var allocations prepare_solution() draws and times (tune_placement());
+                                   // 1 (default) = take the first allocation: the search runs real kernels, holds two sets of arrays for
+                                   // a moment and costs ~1-2 s, so it is the caller's decision (bench.py and the harnesses ask for 6)
     std::vector<float> placement_ms;   // ms per step measured on each set drawn by the last prepare(), and the one kept
     int placement_chosen = 0;
     void tune_placement();
@@ -416,7 +427,8 @@ public:
     void launch_interior(const StageMeta& sm, idx_t t, const Box& ib);
     void time_decomposed_step(const bool* has_lo, const bool* has_hi, int reps, float* ms3);
     // on-chip fusion of two steps per pass (-hip_fuse_steps 2; ykh_starlin2.hpp)
-    idx_t fuse_steps = -1;     // -hip_fuse_steps: 2 = on, 0/1 = off, -1 (default) = where it was measured to pay (radius 1)
+    idx_t fuse_steps = 0;      // -hip_fuse_steps: 2 = on where the solution has such a kernel, 0/1 = off (default: run_solution(a, b) is then
+                               // bit-identical to one call per step; the fused pass contracts its FMAs differently, <= 1e-13 apart in fp64)
     bool can_fuse() const;
     void run_fused(idx_t t0, idx_t npairs, idx_t dir);
     void launch_fused(idx_t t, const void* src, void* slot_b, void* dst, bool store_b);
@@ -450,8 +462,11 @@ public:
     // phase timers: one set of events per (step, stage) of a multi-rank run, read back when run() has drained
     enum { PH_EXT0, PH_EXT1, PH_INT1, PH_WAIT1, PH_PACK0, PH_PACK1, PH_XFER1, PH_UNPACK1, PH_N };
     struct PhaseEvents { hipEvent_t e[PH_N]; bool rec[PH_N]; };
-    std::vector<PhaseEvents> phase_pool;
-    size_t phase_used = 0;
+    std::vector<PhaseEvents> phase_pool;       // a ring of at most PHASE_RING sets: the oldest is folded into `stats` before it is reused
+    enum { PHASE_RING = 64 };
+    size_t phase_used = 0;                     // sets handed out since the last phase_collect()
+    bool phase_timers = true;                  // -[no-]hip_phase_timers: the per-phase events of multi-rank runs (8 records per stage)
+    void phase_fold(const PhaseEvents& ph);
     PhaseEvents* cur_phase = nullptr;          // set by run() around a stage; exchange_halos() records into it
     void phase_mark(int which, hipStream_t st);
     PhaseEvents* phase_next();

@@ -29,6 +29,17 @@ std::string version_string() { return "4.05.04-cdna4_hip"; }
 
 static inline idx_t ceil_div(idx_t a, idx_t b) { return (a + b - 1) / b; }
 
+// Sets a member flag for a scope and puts the old value back on every way out (a throwing launch must not leave
+// `in_outer_loop`, `launching_exterior`, ... set for the calls that follow).
+template <typename T>
+struct ScopedSet {
+    T& ref; T old;
+    ScopedSet(T& r, T v) : ref(r), old(r) { ref = v; }
+    ~ScopedSet() { ref = old; }
+    ScopedSet(const ScopedSet&) = delete;
+    ScopedSet& operator=(const ScopedSet&) = delete;
+};
+
 // grid of the point kernels / cond_bb_kernel over a box (see point_of_thread(), ykh_device.hpp)
 static dim3 point_grid(const Box& b, int lane_dim) {
     const idx_t n[3] = {b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]};
@@ -48,17 +59,8 @@ Env::Env() {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         YKH_THROW("no HIP device is visible: the cdna4_hip kernel library needs an AMD GPU (there is no CPU fallback)");
-    // One process per GPU: a launcher-started rank binds to its own GPU before the first allocation (otherwise every
-    // rank of a node would first open a context on GPU 0).  Same variables as yk_env_init_from_launcher().
-    {
-        auto geti = [](std::initializer_list<const char*> names, int dflt) {
-            for (auto n : names) { const char* v = getenv(n); if (v && *v) return atoi(v); }
-            return dflt;
-        };
-        const int world = geti({"WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS"}, 1);
-        const int lrank = geti({"LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID"}, -1);
-        if (world > 1 && lrank >= 0) (void)hipSetDevice(lrank % ndev);
-    }
+    // The env lives on the device that is current when it is created -- the one the host (torch, the application) chose.  Binding
+    // a launcher-started rank to "its" GPU is yk_env_init_from_launcher()'s job (ykh_launch.cpp), i.e. yk_factory::new_env()'s.
     (void)hipGetDevice(&device);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) num_cus = prop.multiProcessorCount;
@@ -216,7 +218,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                                "bind_inner_threads", "bundle_allocs", "init_scratch_vars", "auto_tune",
                                "allow_addl_padding", "round_up_temporal_angles", "print_suffixes", "verbose",
                                "exchange_halos", "auto_tune_each_stage", "trace", "hip_direct_halo", "hip_thin_slab_point_kernel", "hip_round_launches",
-                               "hip_step_timers", "hip_fast_div"};
+                               "hip_step_timers", "hip_phase_timers", "hip_fast_div"};
     const char* int_opts[] = {"hip_placement_trials", "hip_var_skew", "hip_step_graphs", "hip_pitch_extra", "hip_ext_streams", "hip_comm_cus", "hip_fuse_steps", "hip_overlap_splits", "min_exterior", "max_threads", "outer_threads", "inner_threads", "numa_pref",
                               "auto_tune_radius", "thread_divisor", "block_threads", "hip_xchunk", "device_thread_limit"};
     const char* dbl_opts[] = {"auto_tune_trial_secs"};
@@ -239,6 +241,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                     else if (b == "force_scalar") { force_scalar = val; }
                     else if (b == "auto_tune") { auto_tune = val; tune_at_prepare = val; }   // -no-auto_tune: no timing pass at all
                     else if (b == "hip_step_timers") step_timers = val;
+                    else if (b == "hip_phase_timers") phase_timers = val;
                     else if (b == "trace") env->trace = val;
                     else if (b == "hip_direct_halo") { direct_halo = val; invalidate(); }
                     else if (b == "hip_thin_slab_point_kernel") thin_slab_point_kernel = val;
@@ -345,8 +348,11 @@ std::string Solution::get_command_line_help() const {
           "                       one-off timing of small grids / generic stencils: static default shapes, reproducible)\n"
           " -hip_fuse_steps <n>   2: two time steps per pass, fused on chip, for solutions that have such a kernel (3axis family;\n"
           "                       one rank); the in-between step stays on chip, an odd last step runs the plain kernel.\n"
-          "                       0: never.  Default: on for radius-1 stencils (measured 1.2-1.3x), off otherwise\n"
+          "                       0: never (default: a call over several steps is then bit-identical to one call per step;\n"
+          "                       the fused pass differs in the last bits).  Measured 1.2-1.3x at radius 1, 0.6-0.8x at radius 4\n"
           " -[no-]hip_step_timers record one HIP event per step (per-step times of the last run)\n"
+          " -[no-]hip_phase_timers multi-rank runs: HIP events around exterior / interior / pack / transport / unpack / wait of\n"
+          "                       every stage (yk_stats time breakdown; a ring of 64 event sets; default on)\n"
           " -hip_step_graphs <n>  1: one-rank runs of several steps are captured once into a hipGraph (whole slot periods, up to\n"
           "                       ~256 launches) and replayed, one host call per replay; 0: plain launches.  Default: on for rank\n"
           "                       boxes of up to 2^20 points (measured: 64^3 +13 %, 128^3 and larger +-0.5 %).  Bit-identical.\n"
@@ -355,7 +361,8 @@ std::string Solution::get_command_line_help() const {
           " -hip_variant <name>   force a kernel variant     -hip_xchunk <n>  x-march chunk length\n"
           " -hip_placement_trials <n>         prepare_solution() allocates the vars n times (from 256 MiB in total, memory permitting),\n"
           "                                   times a step on each set and keeps the fastest: where the arrays happen to lie in\n"
-          "                                   memory is worth 3-4 % of a step (default 6; 1: take the first allocation)\n"
+          "                                   memory is worth 3-4 % of a step (default 1: take the first allocation; the search\n"
+          "                                   runs trial kernels and briefly holds two sets of arrays -- bench.py and the harnesses pass 6)\n"
           " -[no-]hip_fast_div                fp32 divisions as a * v_rcp_f32(b), <= 1.5 ulp, in the kernel shapes that have such a\n"
           "                                   form (ssg's defaults: 8 divisions per point were a third of the instructions); off: the\n"
           "                                   correctly rounded shapes, the reference's own arithmetic (default on)\n"
@@ -378,7 +385,7 @@ std::string Solution::get_command_line_values() const {
     for (int d = 0; d < ndd; d++) os << " -nr" << domain_dim_names[d] << " " << num_ranks[d];
     for (int d = 0; d < ndd; d++) os << " -ri" << domain_dim_names[d] << " " << rank_index[d];
     for (int d = 0; d < ndd; d++) os << " -b" << domain_dim_names[d] << " " << block_size[d + 1];
-    if (fuse_steps >= 0) os << " -hip_fuse_steps " << fuse_steps;
+    if (fuse_steps > 0) os << " -hip_fuse_steps " << fuse_steps;
     if (step_graphs >= 0) os << " -hip_step_graphs " << step_graphs;
     if (!fast_div) os << " -no-hip_fast_div";
     os << (overlap_comms ? " -overlap_comms" : " -no-overlap_comms") << " -min_exterior " << min_exterior
@@ -438,7 +445,7 @@ void Solution::tune_placement() {
     for (size_t p = 0; p < impl.parts.size(); p++) if (part_variant[p] < 0) return;
     std::vector<Var*> mv;
     size_t total = 0;
-    for (auto& v : vars) if (!v->fixed_size && v->is_allocated()) { mv.push_back(v.get()); total += v->bytes(); }
+    for (auto& v : vars) if (!v->fixed_size && v->is_allocated() && !v->fuse_group) { mv.push_back(v.get()); total += v->bytes(); }
     for (auto& v : scratch_vars) if (v->is_allocated()) { mv.push_back(v.get()); total += v->bytes(); }
     if (mv.empty()) return;
     struct Ev {
@@ -464,11 +471,13 @@ void Solution::tune_placement() {
         }
         return ms_min;
     };
-    // a set of allocations = (alloc_ptr, dptr) per var; the vars always point at the set being timed
-    typedef std::vector<std::pair<void*, void*>> PtrSet;
-    auto current = [&]() { PtrSet s; for (auto* v : mv) s.push_back({v->alloc_ptr, v->dptr}); return s; };
-    auto attach = [&](const PtrSet& s) { for (size_t k = 0; k < mv.size(); k++) { mv[k]->alloc_ptr = s[k].first; mv[k]->dptr = s[k].second; } };
-    auto free_set = [&](PtrSet& s) { for (auto& p : s) if (p.first) (void)hipFree(p.first); s.clear(); };
+    // a set of allocations = (owner, alloc_ptr, dptr) per var; the vars always point at the set being timed; a set nobody
+    // points at any more is freed when its owners go (Var::own_allocation)
+    struct PlacedVar { std::shared_ptr<void> own; void* alloc; void* data; };
+    typedef std::vector<PlacedVar> PtrSet;
+    auto current = [&]() { PtrSet s; for (auto* v : mv) s.push_back({v->alloc_owner, v->alloc_ptr, v->dptr}); return s; };
+    auto attach = [&](const PtrSet& s) { for (size_t k = 0; k < mv.size(); k++) mv[k]->adopt_storage(s[k].own, s[k].alloc, s[k].data, mv[k]->alloc_bytes); };
+    auto free_set = [&](PtrSet& s) { s.clear(); };
     PtrSet best = current();
     // A GPU that idled is still raising its clocks: step until the step time has settled (three groups of steps within 0.5 %,
     // 1 s at most) -- otherwise the sets timed later simply look faster (seen on a cold box: the "best" set then ran 4 % slower
@@ -496,7 +505,7 @@ void Solution::tune_placement() {
             const size_t skew = (size_t)((char*)v->dptr - (char*)v->alloc_ptr), nb = std::max<size_t>(v->bytes(), 256);
             void* p = nullptr;
             if (hipMalloc(&p, nb + skew) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
-            cand.push_back({p, (char*)p + skew});
+            cand.push_back({Var::own_allocation(p), p, (char*)p + skew});
             if (hipMemsetAsync((char*)p + skew, 0, nb, compute_stream) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
         }
         if (!ok) { free_set(cand); break; }
@@ -519,6 +528,9 @@ void Solution::tune_placement() {
 // ------------------------------------------------------------------ prepare / end
 void Solution::prepare() {
     for (auto& h : before_prepare) h(*this);
+    in_outer_loop = launching_exterior = launching_interior = false;
+    cur_outer = 0;
+    cur_phase = nullptr;
     setup_rank();
     // solution-wide pads = max halo over all vars, scratch vars included (see Var::compute_geometry): every var
     // over all domain dims then has the same strides, which the kernels rely on (P::group_full)
@@ -557,6 +569,7 @@ void Solution::prepare() {
         for (auto& v : vars) movable += v->fixed_size ? 0 : 1;
         for (auto* v : need_alloc) { v->allocate(); total += v->bytes(); }
         placed = !need_alloc.empty() && need_alloc.size() == movable && total >= ((size_t)256 << 20);
+        for (auto& v : vars) if (v->fuse_group) placed = false;      // storage shared with another solution's var stays where it is
     }
     free_halo_buffers();
     alloc_halo_buffers();
@@ -842,10 +855,9 @@ void Solution::launch_part(int part, idx_t t, const Box& box_in, hipStream_t s) 
         // 4 domain dims: the kernels sweep (x, y, z); the outermost dim is a loop of launches, every access group's base
         // pointer following it (fill_part_args).  Planes of one step are independent (reads and writes are in different
         // step slots).
-        in_outer_loop = true;
+        ScopedSet<bool> in_loop(in_outer_loop, true);
+        ScopedSet<idx_t> outer(cur_outer, 0);
         for (cur_outer = 0; cur_outer < local_size[3]; cur_outer++) launch_part(part, t, box_in, s);
-        cur_outer = 0;
-        in_outer_loop = false;
         return;
     }
     const PartMeta& pm = *impl.parts[part].meta;
@@ -912,7 +924,7 @@ Box Solution::interior_for(const bool* has_lo, const bool* has_hi) const {
 }
 // exterior slabs first (context.cpp:377-444) ...
 void Solution::launch_exterior(const StageMeta& sm, idx_t t, const Box& ib) {
-    launching_exterior = true;
+    ScopedSet<bool> ext(launching_exterior, true);
     Box rem = rank_box();
     for (int d = 0; d < ndd; d++) {
         if (ib.lo[d] > rem.lo[d]) {
@@ -926,7 +938,6 @@ void Solution::launch_exterior(const StageMeta& sm, idx_t t, const Box& ib) {
             rem.hi[d] = ib.hi[d];
         }
     }
-    launching_exterior = false;
 }
 // ... then the interior, while the halos travel.  The marching kernels keep one workgroup per CU resident for a whole
 // launch, so a single interior launch would leave no CU for the comm stream until it ends: the interior is split along x
@@ -955,13 +966,12 @@ int Solution::launch_exterior_concurrent(const StageMeta& sm, idx_t t, const Box
         YKH_HIP(hipEventRecord(ext_events[n], ext_streams[n]));
         n++;
     };
-    launching_exterior = true;
+    ScopedSet<bool> ext(launching_exterior, true);
     Box rem = rank_box();
     for (int d = 0; d < ndd; d++) {
         if (ib.lo[d] > rem.lo[d]) { Box s = rem; s.hi[d] = ib.lo[d]; slab(s); rem.lo[d] = ib.lo[d]; }
         if (ib.hi[d] < rem.hi[d]) { Box s = rem; s.lo[d] = ib.hi[d]; slab(s); rem.hi[d] = ib.hi[d]; }
     }
-    launching_exterior = false;
     return n;
 }
 // (parts that fill scratch vars share those arrays between the slabs: such stages keep the serial order)
@@ -974,14 +984,13 @@ int Solution::exterior_mode(const StageMeta& sm) const {
 void Solution::launch_interior(const StageMeta& sm, idx_t t, const Box& ib) {
     const idx_t nxi = ib.hi[0] - ib.lo[0];
     const idx_t nsplit = std::max<idx_t>(1, std::min<idx_t>(overlap_splits, nxi / 64));
-    launching_interior = true;
+    ScopedSet<bool> inter(launching_interior, true);
     for (idx_t c = 0; c < nsplit; c++) {
         Box b = ib;
         b.lo[0] = ib.lo[0] + nxi * c / nsplit;
         b.hi[0] = ib.lo[0] + nxi * (c + 1) / nsplit;
         for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, b, compute_stream);
     }
-    launching_interior = false;
 }
 // What the compute side of one step costs a rank with neighbours on the given sides -- the same launches run() issues,
 // without any communication -- against the undivided box.  tools/decomp_cost.py; ms[0] = exterior, ms[1] = interior,
@@ -1027,13 +1036,22 @@ void Solution::time_decomposed_step(const bool* has_lo, const bool* has_hi, int 
 // (src/kernel/lib/context.hpp:319-328); here the phases are asynchronous, so each (step, stage) of a multi-rank run
 // gets HIP events on the stream the phase runs on; they are read once run() has drained the streams.
 Solution::PhaseEvents* Solution::phase_next() {
-    if (phase_used == phase_pool.size()) {
+    if (!phase_timers) return nullptr;
+    // A ring: run_solution(0, 99999) must not create 800 000 events.  Set number k of a run lives in slot k % PHASE_RING; before
+    // a slot is reused its times are folded into `stats` (its events are PHASE_RING stages old: the wait is almost never one).
+    const size_t slot = phase_used % PHASE_RING;
+    if (slot == phase_pool.size()) {
         PhaseEvents ph;
         for (int i = 0; i < PH_N; i++) { ph.e[i] = nullptr; ph.rec[i] = false; }
         for (int i = 0; i < PH_N; i++) YKH_HIP(hipEventCreate(&ph.e[i]));
         phase_pool.push_back(ph);
+    } else if (phase_used >= PHASE_RING) {
+        PhaseEvents& old = phase_pool[slot];
+        for (int i = 0; i < PH_N; i++) if (old.rec[i]) YKH_HIP(hipEventSynchronize(old.e[i]));
+        phase_fold(old);
     }
-    PhaseEvents* ph = &phase_pool[phase_used++];
+    phase_used++;
+    PhaseEvents* ph = &phase_pool[slot];
     for (int i = 0; i < PH_N; i++) ph->rec[i] = false;
     return ph;
 }
@@ -1042,22 +1060,25 @@ void Solution::phase_mark(int which, hipStream_t st) {
     YKH_HIP(hipEventRecord(cur_phase->e[which], st));
     cur_phase->rec[which] = true;
 }
-void Solution::phase_collect() {
-    auto span = [](const PhaseEvents& ph, int a, int b) -> double {
+void Solution::phase_fold(const PhaseEvents& ph) {
+    auto span = [&](int a, int b) -> double {
         if (!ph.rec[a] || !ph.rec[b]) return 0.0;
         float ms = 0;
         if (hipEventElapsedTime(&ms, ph.e[a], ph.e[b]) != hipSuccess) { (void)hipGetLastError(); return 0.0; }
         return ms > 0 ? ms * 1e-3 : 0.0;
     };
-    for (size_t i = 0; i < phase_used; i++) {
-        const PhaseEvents& ph = phase_pool[i];
-        stats.exterior_secs += span(ph, PH_EXT0, PH_EXT1);
-        stats.interior_secs += span(ph, PH_EXT1, PH_INT1);
-        stats.halo_wait_secs += span(ph, PH_INT1, PH_WAIT1);
-        const double pack = span(ph, PH_PACK0, PH_PACK1), xfer = span(ph, PH_PACK1, PH_XFER1), unpack = span(ph, PH_XFER1, PH_UNPACK1);
-        stats.halo_pack_secs += pack; stats.halo_xfer_secs += xfer; stats.halo_unpack_secs += unpack;
-        stats.halo_secs += pack + xfer + unpack;
-    }
+    stats.exterior_secs += span(PH_EXT0, PH_EXT1);
+    stats.interior_secs += span(PH_EXT1, PH_INT1);
+    stats.halo_wait_secs += span(PH_INT1, PH_WAIT1);
+    const double pack = span(PH_PACK0, PH_PACK1), xfer = span(PH_PACK1, PH_XFER1), unpack = span(PH_XFER1, PH_UNPACK1);
+    stats.halo_pack_secs += pack; stats.halo_xfer_secs += xfer; stats.halo_unpack_secs += unpack;
+    stats.halo_secs += pack + xfer + unpack;
+}
+// (called when run() has drained the streams: every set still in the ring is complete)
+void Solution::phase_collect() {
+    const size_t live = std::min<size_t>(phase_used, phase_pool.size());
+    for (size_t i = 0; i < live; i++) phase_fold(phase_pool[i]);
+    for (auto& ph : phase_pool) for (int i = 0; i < PH_N; i++) ph.rec[i] = false;
     phase_used = 0;
 }
 
@@ -1068,12 +1089,8 @@ void Solution::phase_collect() {
 // single rank never updates) and the layout is restored at the end.  The LAST pass also stores S(t+1), so that after
 // run_solution() both step slots hold what a plain run leaves there.
 bool Solution::can_fuse() const {
-    if (fuse_steps == 0 || fuse_steps == 1 || env->nranks != 1 || ndd != 3 || force_scalar) return false;
+    if (fuse_steps < 2 || env->nranks != 1 || ndd != 3 || force_scalar) return false;
     if (impl.parts.size() != 1 || !impl.parts[0].fused2.launch || meta->n_stages != 1) return false;
-    // default: only where the fused pass was measured faster than two plain sweeps -- the 7-point stencil (radius 1:
-    // 1.30x at 512^3, 1.18x at 1024^3; radius 4: 0.6x, the two levels no longer fit the register file comfortably) -- and
-    // not when the caller named a kernel shape
-    if (fuse_steps < 0 && (impl.parts[0].fused2.xr > 1 || !variant_override.empty())) return false;
     const PartMeta& pm = *impl.parts[0].meta;
     for (auto& v : vars)
         if (v->meta == &meta->vars[pm.groups[0].var]) return v->nslots == 2 && v->is_allocated();

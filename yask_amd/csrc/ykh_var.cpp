@@ -89,7 +89,15 @@ Var::Var(Solution* s, const std::string& nm, const std::vector<std::string>& dna
     dirty.assign(nslots, 0);
 }
 
-Var::~Var() { release(); }
+Var::~Var() {
+    // leave the fuse group; the storage lives on while another var of the group holds it
+    if (fuse_group) {
+        auto& g = *fuse_group;
+        g.erase(std::remove(g.begin(), g.end(), this), g.end());
+        fuse_group.reset();
+    }
+    drop_storage_refs();
+}
 
 int Var::elem_bytes() const { return soln->elem_bytes(); }
 
@@ -153,6 +161,43 @@ void Var::compute_geometry() {
     for (int d = 0; d < soln->ndd; d++) origin_elems += pad_l[d] * stride[d];
 }
 
+std::shared_ptr<void> Var::own_allocation(void* alloc) {
+    return std::shared_ptr<void>(alloc, [](void* p) { if (p) (void)hipFree(p); });
+}
+// The storage of this var -- and of every var fused with it -- becomes [data, data + nbytes) inside `alloc`.
+void Var::adopt_storage(std::shared_ptr<void> owner, void* alloc, void* data, size_t nbytes) {
+    auto set = [&](Var& m) { m.alloc_owner = owner; m.alloc_ptr = alloc; m.dptr = data; m.alloc_bytes = nbytes; };
+    if (fuse_group) for (Var* m : *fuse_group) set(*m);
+    else set(*this);
+}
+void Var::drop_storage_refs() {
+    alloc_owner.reset();
+    alloc_ptr = nullptr;
+    dptr = nullptr;
+    alloc_bytes = 0;
+    if (scratch) { (void)hipFree(scratch); scratch = nullptr; }
+    mirror_.clear();
+    raw_exposed_ = false;
+}
+// fuse_vars(): from here on this var and `src` are two names for one var (src/kernel/lib/yk_var_apis.cpp:334-367 points
+// both API objects at one YkVarBase): one allocation, one valid-step window, one set of dirty flags.
+void Var::fuse_with(Var& src) {
+    if (&src == this || (fuse_group && fuse_group == src.fuse_group)) return;
+    // leave my old group, release what I held
+    if (fuse_group) {
+        auto& g = *fuse_group;
+        g.erase(std::remove(g.begin(), g.end(), this), g.end());
+        fuse_group.reset();
+    }
+    drop_storage_refs();
+    if (!src.fuse_group) { src.fuse_group = std::make_shared<std::vector<Var*>>(); src.fuse_group->push_back(&src); }
+    fuse_group = src.fuse_group;
+    fuse_group->push_back(this);
+    alloc_owner = src.alloc_owner; alloc_ptr = src.alloc_ptr; dptr = src.dptr; alloc_bytes = src.alloc_bytes;
+    first_valid_step = src.first_valid_step;
+    dirty = src.dirty;
+}
+
 void Var::allocate() {
     release();
     size_t nb = bytes();
@@ -161,25 +206,20 @@ void Var::allocate() {
     // the solution's arrays -- which a multi-var kernel reads at the same time -- does not start in the same position of the
     // allocation granule in all of them (tools/placement_probe.py)
     const size_t skew = soln->var_skew > 0 ? (size_t)((ordinal * soln->var_skew) % 64) * 256 : 0;
-    YKH_HIP(hipMalloc(&alloc_ptr, nb + skew));
-    dptr = (char*)alloc_ptr + skew;
-    alloc_bytes = nb;
+    void* ap = nullptr;
+    YKH_HIP(hipMalloc(&ap, nb + skew));
+    adopt_storage(own_allocation(ap), ap, (char*)ap + skew, nb);
     // Zero on the solution's own stream: hipMemset() runs on the NULL stream, which the solution's
     // non-blocking streams do not synchronise with -- a multi-GB memset was still clearing the tail of the
     // allocation while the first init kernel had already written it (seen at >= 512^3).
     YKH_HIP(hipMemsetAsync(dptr, 0, nb, soln->compute_stream));
     YKH_HIP(hipStreamSynchronize(soln->compute_stream));
-    mirror_.clear();
-    raw_exposed_ = false;
 }
 
+// release_storage(): "after fusing, calling release_storage() on this var or the source var will apply to both"
 void Var::release() {
-    if (alloc_ptr) { (void)hipFree(alloc_ptr); alloc_ptr = nullptr; }
-    dptr = nullptr;
-    if (scratch) { (void)hipFree(scratch); scratch = nullptr; }
-    alloc_bytes = 0;
-    mirror_.clear();
-    raw_exposed_ = false;
+    if (fuse_group) for (Var* m : *fuse_group) m->drop_storage_refs();
+    else drop_storage_refs();
 }
 
 int Var::slot_of(idx_t t) const { return has_step ? (int)imod_flr(t, nslots) : 0; }
@@ -193,6 +233,7 @@ void Var::update_valid_step(idx_t t) {
     if (!has_step) return;
     if (t < first_valid_step) first_valid_step = t;
     else if (t > last_valid_step()) first_valid_step = t - nslots + 1;
+    if (fuse_group) for (Var* m : *fuse_group) m->first_valid_step = first_valid_step;
 }
 
 int Var::dim_posn(const std::string& dim, bool must_exist) const {
@@ -553,8 +594,16 @@ idx_t Var::compare(const Var& ref, double eps) const {
     return (idx_t)h;
 }
 
-void Var::set_dirty(bool d, idx_t t) { dirty[slot_of(t)] = d ? 1 : 0; }
-void Var::set_dirty_all(bool d) { std::fill(dirty.begin(), dirty.end(), d ? 1 : 0); }
+// (a fuse group is one var: data written through one name needs its halos exchanged under every name)
+void Var::set_dirty(bool d, idx_t t) {
+    const int sl = slot_of(t);
+    if (fuse_group) { for (Var* m : *fuse_group) if (sl < (int)m->dirty.size()) m->dirty[sl] = d ? 1 : 0; }
+    else dirty[sl] = d ? 1 : 0;
+}
+void Var::set_dirty_all(bool d) {
+    if (fuse_group) { for (Var* m : *fuse_group) std::fill(m->dirty.begin(), m->dirty.end(), d ? 1 : 0); }
+    else std::fill(dirty.begin(), dirty.end(), d ? 1 : 0);
+}
 bool Var::is_dirty(idx_t t) const { return dirty[slot_of(t)] != 0; }
 
 // Host mirror for yk_var::get_raw_storage_buffer() (src/kernel/lib/yk_var.hpp:2624).  In the reference the raw pointer IS the
@@ -572,17 +621,26 @@ void* Var::host_mirror() {
     after_device_write();
     return mirror_.data();
 }
+// (fused vars: a raw buffer handed out under one name is pushed / pulled whichever name the call goes through)
 void Var::before_device_use() const {
-    if (!raw_exposed_ || !dptr || mirror_.size() != bytes()) return;
-    YKH_HIP(hipStreamSynchronize(soln->compute_stream));
-    YKH_HIP(hipMemcpyAsync(dptr, mirror_.data(), bytes(), hipMemcpyHostToDevice, soln->compute_stream));
-    YKH_HIP(hipStreamSynchronize(soln->compute_stream));
+    auto push = [](const Var& m) {
+        if (!m.raw_exposed_ || !m.dptr || m.mirror_.size() != m.bytes()) return;
+        YKH_HIP(hipStreamSynchronize(m.soln->compute_stream));
+        YKH_HIP(hipMemcpyAsync(m.dptr, m.mirror_.data(), m.bytes(), hipMemcpyHostToDevice, m.soln->compute_stream));
+        YKH_HIP(hipStreamSynchronize(m.soln->compute_stream));
+    };
+    if (fuse_group) for (const Var* m : *fuse_group) push(*m);
+    else push(*this);
 }
 void Var::after_device_write() {
-    if (!raw_exposed_ || !dptr || mirror_.size() != bytes()) return;
-    YKH_HIP(hipStreamSynchronize(soln->compute_stream));
-    YKH_HIP(hipMemcpyAsync(mirror_.data(), dptr, bytes(), hipMemcpyDeviceToHost, soln->compute_stream));
-    YKH_HIP(hipStreamSynchronize(soln->compute_stream));
+    auto pull = [](Var& m) {
+        if (!m.raw_exposed_ || !m.dptr || m.mirror_.size() != m.bytes()) return;
+        YKH_HIP(hipStreamSynchronize(m.soln->compute_stream));
+        YKH_HIP(hipMemcpyAsync(m.mirror_.data(), m.dptr, m.bytes(), hipMemcpyDeviceToHost, m.soln->compute_stream));
+        YKH_HIP(hipStreamSynchronize(m.soln->compute_stream));
+    };
+    if (fuse_group) for (Var* m : *fuse_group) pull(*m);
+    else pull(*this);
 }
 // Kept for callers of round 1's extension: pushes the host copy now (before_device_use() does it anyway).
 void Var::sync_mirror_to_device() {

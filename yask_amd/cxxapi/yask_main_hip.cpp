@@ -103,6 +103,9 @@ int main(int argc, char** argv) {
                    " -init_seed <x>  -validate|-v  -sleep <secs>\n" << soln->get_command_line_help();
             return 0;
         }
+        // (the harness asks for the var-placement search -- a library default since round 3 is "first allocation"; several ranks may
+        //  share one device in tests, and the search briefly holds two sets of arrays: one rank per process only)
+        if (world == 1) soln->apply_command_line_options("-hip_placement_trials 6");
         string rem = soln->apply_command_line_options(o.rest);
         if (!rem.empty())
             throw yask_exception("YASK error: extraneous parameter(s): '" + rem + "'; run with '-help' option for usage");

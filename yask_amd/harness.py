@@ -79,6 +79,8 @@ def main(argv=None):
         fac = yk_factory(o["stencil"])
         env, transport = ydist.new_env(fac, "rccl")
         soln = fac.new_solution(env)
+        if world == 1:      # (the var-placement search is opt-in in the library; see yask_main_hip.cpp)
+            soln.apply_command_line_options("-hip_placement_trials 6")
         rem = soln.apply_command_line_options(" ".join(rest))
         if rem:
             raise RuntimeError(f"YASK error: extraneous parameter(s): '{rem}'; run with '-help' option for usage")
