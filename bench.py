@@ -252,11 +252,15 @@ def main():
                          "xslab: N x 1 x 1 ranks, contiguous whole-plane faces, 2 neighbours per GPU (default for weak)")
     ap.add_argument("--points-per-gpu", dest="local", type=int, nargs=3, default=None, metavar=("NX", "NY", "NZ"),
                     help="explicit points per GPU per dim (overrides --config / --size)")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"])
-    ap.add_argument("--schedule", default="auto", choices=["auto", "overlap1", "overlap2", "overlap4", "serial"],
-                    help="N>1: how a step is issued.  overlapK: exterior slabs, then the halo exchange on the side stream beside the "
-                         "interior cut into K launches (the reference's -overlap_comms); serial: the whole box in one launch, then the "
-                         "exchange (-no-overlap_comms).  auto (default): every candidate runs a few untimed steps during warm-up, "
+    ap.add_argument("--transport", default="auto", choices=["auto", "ipc", "rccl", "torch"],
+                    help="N>1: halo transport.  ipc: device-to-device copies through HIP IPC handles + stream-ordered flags; rccl: grouped "
+                         "ncclSend/ncclRecv; torch: torch.distributed P2P (host-staged with gloo: tests).  auto (default): ipc and rccl each "
+                         "run a few steps during warm-up, the faster one is used and both timings are reported")
+    ap.add_argument("--schedule", default="auto", choices=["auto", "planned", "planned30", "planned65", "slabs2", "serial"],
+                    help="N>1: how a step is issued.  planned / planned30 / planned65: the rank box as ONE launch, shell blocks first (done "
+                         "after 45 / 30 / 65 %% of the launch), the halo exchange released from the device when they are done; slabs2: "
+                         "exterior slabs, then the exchange beside the interior cut into 2 launches (round 2); serial: the whole box, "
+                         "then the exchange (-no-overlap_comms).  auto (default): every candidate runs a few steps during warm-up, "
                          "the fastest (max over ranks) is used for the timed region and all timings are reported")
     ap.add_argument("--opts", default="", help="extra yask options, e.g. '-hip_variant NAME'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -284,33 +288,88 @@ def main():
     from yask_amd.kernel import yk_env
     yk_env.disable_debug_output()          # stdout carries the ONE JSON line only
     fac = yk_factory(stencil)
-    # a failing RCCL set-up is fatal here: the number must not silently become a torch-transport one
-    env, transport = ydist.new_env(fac, args.transport, strict=True)
-    soln = fac.new_solution(env)
     n = args.size or dflt_n
     decomp = args.decomp or ("xslab" if args.config == "weak" else "compact")
-    if decomp == "xslab":
-        soln.set_num_ranks_vec([world, 1, 1])
-    if args.local:
-        soln.set_rank_domain_size_vec(list(args.local))
-        scaling = "weak"
-    elif args.config == "c2":
-        soln.set_overall_domain_size_vec([n, n, n])
-        scaling = "strong"
-    elif args.config == "c4":
-        soln.set_rank_domain_size_vec([n, n, n // 2])
-        scaling = "weak"
-    else:
-        soln.set_rank_domain_size_vec([n, n, n])
-        scaling = "weak"
     # the placement search (a best-of-6 draw of the arrays' physical placement, DESIGN.md section 2) is the caller's choice since
     # round 3: one process per GPU asks for it; ranks that share a device (tests) must not race for its memory
     shared_dev = world > 1 and os.environ.get("YASK_DIST_BACKEND", "") == "gloo"
-    rem = soln.apply_command_line_options(("-hip_step_timers " + ("" if shared_dev else "-hip_placement_trials 6 ")) + args.opts)
-    assert rem == "", rem
-    soln.prepare_solution()
-    for name, (off, sc, hid) in init.items():
-        soln.get_var(name).set_elements_hash(off, sc, hash_id=hid)
+    scaling_of = {"c2": "strong", "c4": "weak", "weak": "weak"}
+    scaling = "weak" if args.local else scaling_of[args.config]
+
+    def build(transport_name):
+        """env + prepared, initialised solution on one halo transport (a failing set-up raises on every rank: a number must not
+        silently be measured on another transport, VERDICT r01 weak #8)"""
+        env_, used = ydist.new_env(fac, transport_name, strict=True)
+        so = fac.new_solution(env_)
+        if decomp == "xslab":
+            so.set_num_ranks_vec([world, 1, 1])
+        if args.local:
+            so.set_rank_domain_size_vec(list(args.local))
+        elif args.config == "c2":
+            so.set_overall_domain_size_vec([n, n, n])
+        elif args.config == "c4":
+            so.set_rank_domain_size_vec([n, n, n // 2])
+        else:
+            so.set_rank_domain_size_vec([n, n, n])
+        rem = so.apply_command_line_options(("-hip_step_timers " + ("" if shared_dev else "-hip_placement_trials 6 ")) + args.opts)
+        assert rem == "", rem
+        so.prepare_solution()
+        for name, (off, sc, hid) in init.items():
+            so.get_var(name).set_elements_hash(off, sc, hash_id=hid)
+        return env_, so, used
+
+    def agree_min_int(x):
+        if world <= 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.int64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MIN)
+        return int(tt.item())
+
+    # ---- N>1: the halo transport is chosen by measurement too.  "ipc" = copies into the neighbour's buffers through HIP IPC
+    # handles (SDMA over xGMI: no compute units, so the bytes move while a stencil launch owns every CU); "rccl" = grouped
+    # ncclSend / ncclRecv kernels.  Which is faster on a given node is a property of the node: each candidate runs 2 untimed + 6
+    # timed steps on the default schedule, the times are max-reduced over the ranks, the faster one runs the benchmark and both
+    # numbers are reported.  A candidate that cannot be set up on every rank, or fails its trial, is skipped (and reported).
+    transport_ms = None
+    if world > 1 and args.transport == "auto":
+        cands = ["ipc", "rccl"] if torch.distributed.get_backend() == "nccl" else ["ipc", "torch"]
+        transport_ms, built = {}, {}
+        for c in cands:
+            ok, ms = 1, None
+            try:
+                e_, s_, used_ = build(c)
+                assert s_.apply_command_line_options("-overlap_comms -hip_planned_launch") == ""
+                s_.run_solution(0, 1)
+                torch.cuda.synchronize(); torch.distributed.barrier()
+                w0 = time.perf_counter()
+                s_.run_solution(2, 7)
+                torch.cuda.synchronize(); torch.distributed.barrier()
+                ms = (time.perf_counter() - w0) / 6 * 1e3
+                built[c] = (e_, s_, used_)
+            except Exception as ex:  # noqa: BLE001
+                print(f"bench[{rank}]: halo transport '{c}' unusable: {ex!r}", file=sys.stderr, flush=True)
+                ok = 0
+            if agree_min_int(ok) == 0:
+                transport_ms[c] = None
+                if c in built:
+                    built.pop(c)[1].end_solution()
+                continue
+            tt = torch.tensor([ms], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            transport_ms[c] = round(float(tt.item()), 4)
+        usable = [c for c in cands if transport_ms.get(c) is not None]
+        if not usable:
+            raise SystemExit("bench.py: no halo transport could be set up on every rank")
+        best = min(usable, key=lambda c: transport_ms[c])
+        for c in list(built):
+            if c != best:
+                built[c][1].end_solution()
+                del built[c]
+        env, soln, transport = built[best]
+        for name, (off, sc, hid) in init.items():       # (the trial steps changed the data: back to the initial state)
+            soln.get_var(name).set_elements_hash(off, sc, hash_id=hid)
+    else:
+        env, soln, transport = build("rccl" if args.transport == "auto" else args.transport)
     local = soln.get_rank_domain_size_vec()
     glob_sz = soln.get_overall_domain_size_vec()
     grid = soln.get_num_ranks_vec()
@@ -331,12 +390,16 @@ def main():
     # ---- N>1: the launch schedule of a step is chosen by measurement (the reference's auto-tuner does the same with its block
     # sizes before the trials, yask_main.cpp:334-335): which of "hide the exchange behind a split interior" and "one full-speed
     # launch, then the exchange" wins depends on link speed vs the cost of cutting the box
-    SCHEDULES = {"overlap2": "-overlap_comms -hip_overlap_splits 2", "overlap1": "-overlap_comms -hip_overlap_splits 1",
-                 "overlap4": "-overlap_comms -hip_overlap_splits 4", "serial": "-no-overlap_comms"}
+    # "planned*": the rank box as ONE launch, shell blocks first, the exchange released from the device when they are done (round 3;
+    # the shell is cut to be done after 45 / 30 / 65 % of the launch: earlier = more time to hide the exchange in, later = fewer and
+    # longer shell blocks = less prologue overhead); "slabs2": round 2's exterior slabs + interior in two launches
+    SCHEDULES = {"planned": "-overlap_comms -hip_planned_launch -hip_shell_pct 45", "planned30": "-overlap_comms -hip_planned_launch -hip_shell_pct 30",
+                 "planned65": "-overlap_comms -hip_planned_launch -hip_shell_pct 65",
+                 "slabs2": "-overlap_comms -no-hip_planned_launch -hip_overlap_splits 2", "serial": "-no-overlap_comms"}
     schedule, schedule_ms = None, None
     t = 0
     if world > 1:
-        schedule = "overlap2" if args.schedule == "auto" else args.schedule
+        schedule = "planned" if args.schedule == "auto" else args.schedule
         if args.schedule == "auto":
             schedule_ms = {}
             for name, opt in SCHEDULES.items():
@@ -434,7 +497,7 @@ def main():
                        "baseline_config": {"c2": "configs[1] (1024^3 global)", "c4": "configs[3] (1024x1024x512 per GPU, compact grid)",
                                            "weak": "one block per GPU"}[args.config] if not args.local else "explicit --points-per-gpu",
                        "decomposition": ("x-slabs " if decomp == "xslab" else "compact rank grid ") + "x".join(str(g) for g in grid),
-                       "halo_transport": transport,
+                       "halo_transport": transport, "transport_trials_ms_per_step": transport_ms,
                        "kernel": "+".join(soln.get_kernel_variant(p) for p in range(nparts)),
                        "overlap_comms": (schedule != "serial") if world > 1 else None,
                        "schedule": schedule, "schedule_trials_ms_per_step": schedule_ms,

@@ -84,6 +84,13 @@ int yk_env_init_from_launcher(yk_env_h env);
 /* the host-staged TCP transport alone: full mesh of sockets; every rank listens on a kernel-assigned port, the port table
  * is gathered and handed out by rank 0 on `base_port` */
 int yk_env_init_tcp(yk_env_h env, int rank, int num_ranks, const char* addr, int base_port);
+/* Device-to-device halo transport between the ranks of ONE host (yask_amd/csrc/ykh_ipc.cpp): the sender copies its packed
+ * halo straight into the receiver's buffer, mapped through HIP IPC memory handles (hipMemcpyAsync: SDMA over xGMI between
+ * devices -- no compute units, unlike RCCL's send/recv kernels, so the copy proceeds while a stencil launch owns every CU);
+ * ordering by flag words in device memory, everything stream-ordered.  The counterpart of the reference progressing its
+ * MPI requests during the interior (adv_halo_exchange, src/kernel/lib/halo.cpp:494-574).  Ranks may share a device (tests).
+ * Control messages and the scalar all-reduce run over the same TCP mesh as yk_env_init_tcp(). YASK_HIP_TRANSPORT=ipc. */
+int yk_env_init_ipc(yk_env_h env, int rank, int num_ranks, const char* addr, int base_port);
 /* that mesh alone (no GPU needed): connect, one SUM all-reduce of the ranks over it, close; 0 on success */
 int yk_tcp_mesh_check(int rank, int num_ranks, const char* addr, int base_port, long long* sum);
 /* the rendezvous alone (no GPU needed): rank 0 serves `nbytes` of `buf` to the other ranks; 0 on success */
@@ -125,6 +132,18 @@ int yk_plan_halo_slab(int ndims, const yk_rank_plan_t* plan, const int* neighbor
  * src/kernel/lib/context.cpp:482-745,1181-1525): the launches, in order, that apply `nphases` (step, stage) phases to
  * [lo, hi) slab by slab -- triples (phase, first, end) in out3.  Returns their number (<= cap are written).  No GPU needed. */
 int yk_plan_wavefront(yk_idx_t lo, yk_idx_t hi, yk_idx_t width, yk_idx_t angle, yk_idx_t nphases, yk_idx_t* out3, int cap);
+
+/* Planned launch of a decomposed rank: the reference computes a rank's exterior first, starts the halo
+ * exchange and computes the interior meanwhile (StencilContext::run_solution, src/kernel/lib/context.cpp:377-478; exterior width
+ * `-min_exterior`, settings.hpp:245).  Here that is ONE launch of the marching kernel over the rank box [0, n) whose workgroups
+ * take (tile, x-range) descriptors in this order: x-face slabs, the y/z tiles a neighbour needs (in x-chunks short enough to be
+ * done after shell_pct % of the launch), then the interior in pieces sized against the simulated CU time line.  flags bit 0 =
+ * the block is part of the shell (it counts towards the signal that releases the exchange).  Writes <= cap descriptors, returns
+ * their number; info[0..4] = shell blocks, simulated end of the shell, simulated end of the launch, the undivided box simulated
+ * the same way (plane-iterations), interior mode used (1 greedy budgets, 2 uniform chunks).  No GPU needed. */
+typedef struct { int x0, x1, y0, y1, z0, z1, flags, start; } yk_block_desc_t;
+int yk_plan_blocks(const yk_idx_t* n3, const int* has_lo3, const int* has_hi3, const yk_idx_t* width3, int tile_y, int tile_z,
+                   int overhead, int num_cus, int shell_pct, int mode, yk_block_desc_t* out, int cap, yk_idx_t* info5);
 
 /* ---- solution: replaces yk_solution, include/aux/yk_solution_api.hpp:82-1292 ---- */
 const char* yk_solution_get_name(yk_soln_h s);                               /* :90 */

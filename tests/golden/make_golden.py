@@ -103,6 +103,8 @@ BIG_CASES = [
     ("c2_iso3dfd_1024_s2_lattice", "iso3dfd", "iso3dfd", (1024, 1024, 1024), 2, 32, ["p"]),
     ("c3_3axis_fp64_512_s4_lattice", "3axis_fp64", "3axis", (512, 512, 512), 4, 16, ["A"]),
     ("c5_ssg_256_s3_lattice", "ssg", "ssg", (256, 256, 256), 3, 16, None),
+    # round 3 (VERDICT r02 weak #1 ii): ssg at the size bench.py runs it at, where the kernel shapes are chosen by size
+    ("c5_ssg_512_s3_lattice", "ssg", "ssg", (512, 512, 512), 3, 32, None),
 ]
 
 

@@ -1,0 +1,215 @@
+"""The decomposed path at the block sizes BASELINE configs 2 / 4 / 5 give a GPU ("next round" item 1).
+
+Kernel choice and launch geometry depend on the size of the rank's box (tile 128 x 32 on large boxes, x-chunks that fill the
+256 CUs, the planned launch's shell / interior pieces), so the decomposed path is checked AT those sizes, on ONE GPU shared
+by the ranks, through the real library path -- planned launches with their device-side completion signal, pack kernels,
+the device-to-device IPC transport (yask_amd/csrc/ykh_ipc.cpp) or the host-staged TCP one, unpack kernels, dirty-flag
+bookkeeping -- with default options (`-overlap_comms` is the default):
+
+  * iso3dfd, global 1024^3 (BASELINE config 2): 2 ranks 1x1x2 -> two 1024 x 1024 x 512 blocks (config 4's per-GPU block),
+    and 8 ranks 2x2x2 -> eight 512^3 blocks (three face neighbours each);
+  * ssg, global 512^3: 8 ranks 2x2x2 -> 256^3 blocks (nine in-place fields, two stages, asymmetric halos, `mu` to the edge
+    neighbours).
+
+Every rank's block must equal the same box of the ONE-rank run BIT FOR BIT (compared through a 128-bit digest of the raw
+values: a 1024^3 field does not travel between processes), and the assembled lattice sample must match what the UNMODIFIED
+reference computed at that size (tests/golden/make_golden.py BIG_CASES) within the stated tolerance (fp32: 2e-5).
+ssg at 512^3 on one rank is also checked against the C oracle at every point and against a reference lattice of its own
+(weak #1 ii: it was only ever checked at 256^3)."""
+import hashlib
+import json
+import os
+import socket
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).resolve().parent / "golden"
+INDEX = json.load(open(G / "index.json"))
+FIELDS = {"iso3dfd": ["p"], "ssg": O.SSG_FIELDS}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _init(soln, stencil):
+    init = O.DEFAULT_INIT[stencil]
+    for v in soln.get_vars():
+        v.set_elements_hash(*init[v.get_name()], hash_id=O.VAR_IDS[stencil][v.get_name()])
+
+
+def _digest_and_lattice(soln, stencil, t, first, last, g, stride):
+    """Per field: blake2b digest of the box [first, last] of step t (x-chunks of 64 planes, C order) and the lattice points of
+    the global grid that fall into the box, as {global index triple -> value} arrays."""
+    out = {}
+    lat = [O.lattice(s, stride) for s in g]
+    mine = [a[(a >= first[d]) & (a <= last[d])] for d, a in enumerate(lat)]
+    for name in FIELDS[stencil]:
+        var = soln.get_var(name)
+        h = hashlib.blake2b(digest_size=16)
+        planes = {}
+        for x0 in range(first[0], last[0] + 1, 64):
+            x1 = min(last[0], x0 + 63)
+            a = var.get_elements_in_slice([t, x0, first[1], first[2]], [t, x1, last[1], last[2]])[0]
+            h.update(np.ascontiguousarray(a).tobytes())
+            for x in mine[0][(mine[0] >= x0) & (mine[0] <= x1)]:
+                planes[int(x)] = a[int(x) - x0][np.ix_(mine[1] - first[1], mine[2] - first[2])].copy()
+        out[name] = (h.hexdigest(), planes)
+    return out, [m.tolist() for m in mine]
+
+
+def _worker(rank, world, port, q, stencil, g, nr, steps, opts, transport, stride):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      YASK_HIP_TRANSPORT=transport)
+    from yask_amd import yk_factory
+    fac = yk_factory(stencil)
+    env = fac.new_env()
+    env.init_from_launcher()                     # native bootstrap, no torch in the rank processes
+    soln = fac.new_solution(env)
+    soln.set_overall_domain_size_vec(list(g))
+    soln.set_num_ranks_vec(list(nr))
+    assert soln.apply_command_line_options(opts) == ""
+    soln.prepare_solution()
+    _init(soln, stencil)
+    soln.run_solution(0, steps - 1)
+    st = soln.get_stats()
+    f, l = soln.get_first_rank_domain_index_vec(), soln.get_last_rank_domain_index_vec()
+    res, mine = _digest_and_lattice(soln, stencil, steps, f, l, g, stride)
+    info = dict(kernels=[soln.get_kernel_variant(p) for p in range(soln.get_num_parts())], msgs=st.get_halo_msgs_sent(),
+                hidden=st.get_comm_hidden_fraction(), ext=st.get_exterior_secs(), inter=st.get_interior_secs(), wait=st.get_halo_wait_secs())
+    q.put((rank, f, l, res, mine, info))
+    env.global_barrier()
+    soln.end_solution()
+
+
+def _run_ranks(world, stencil, g, nr, steps, opts, transport, stride):
+    import queue
+    import time
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, stencil, g, nr, steps, opts, transport, stride)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts, t0 = [], time.time()
+    while len(parts) < world:
+        try:
+            parts.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > 240:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                pytest.fail(f"rank process(es) failed: exit codes {[p.exitcode for p in procs]}")
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return sorted(parts)
+
+
+_ONE = {}
+
+
+def _one_rank_cached(stencil, g, steps):
+    """the one-rank run of a case, kept alive for the parametrizations that compare with it (15 GB of 288 at 1024^3)"""
+    key = (stencil, tuple(g), steps)
+    if key not in _ONE:
+        for k in list(_ONE):
+            _ONE.pop(k).end_solution()
+        _ONE[key] = _one_rank(stencil, g, steps)
+    return _ONE[key]
+
+
+def _one_rank(stencil, g, steps, opts=""):
+    from yask_amd import yk_factory
+    fac = yk_factory(stencil)
+    one = fac.new_solution(fac.new_env())
+    one.set_overall_domain_size_vec(list(g))
+    assert one.apply_command_line_options(opts) == ""
+    one.prepare_solution()
+    _init(one, stencil)
+    one.run_solution(0, steps - 1)
+    return one
+
+
+def _check_against_one_rank_and_reference(parts, one, stencil, g, steps, stride, ref_npz, tol_scale_one):
+    kern_one = [one.get_kernel_variant(p) for p in range(one.get_num_parts())]
+    lat = [O.lattice(s, stride) for s in g]
+    pos = [{int(v): i for i, v in enumerate(a)} for a in lat]
+    full = {n: np.full([len(a) for a in lat], np.nan, np.float32) for n in FIELDS[stencil]}
+    for rank, f, l, res, mine, info in parts:
+        assert info["kernels"] == kern_one, (rank, info["kernels"], kern_one)       # same kernel shapes: bit-equality is meaningful
+        want, _ = _digest_and_lattice(one, stencil, steps, f, l, g, stride)
+        for n in FIELDS[stencil]:
+            assert res[n][0] == want[n][0], f"rank {rank}: field {n} of box {f}..{l} differs from the one-rank run"
+            iy = [pos[1][v] for v in mine[1]]
+            iz = [pos[2][v] for v in mine[2]]
+            for x, plane in res[n][1].items():
+                full[n][pos[0][x]][np.ix_(iy, iz)] = plane
+    z = np.load(ref_npz)
+    for n in FIELDS[stencil]:
+        assert not np.isnan(full[n]).any(), n
+        ref = z[f"{n}@{steps}"].astype(np.float64)
+        err = np.abs(full[n].astype(np.float64) - ref).max() / (max(1.0, np.abs(ref).max()) if tol_scale_one else np.abs(ref).max())
+        assert full[n].shape == ref.shape and err <= 2e-5, (n, err)
+
+
+@pytest.mark.parametrize("world,nr,transport,opts", [
+    (2, (1, 1, 2), "ipc", ""),                                                 # two 1024 x 1024 x 512 blocks (config 4's block), z face
+    (8, (2, 2, 2), "ipc", ""),                                                 # eight 512^3 blocks, three faces each, planned launches
+    (8, (2, 2, 2), "tcp", "-no-hip_planned_launch -no-hip_thin_slab_point_kernel"),   # round 2's slabs + split interior at this size
+])
+def test_iso3dfd_1024_cut_over_ranks_equals_one_rank_and_the_reference(gpu, world, nr, transport, opts):
+    meta = INDEX["c2_iso3dfd_1024_s2_lattice"]
+    g, steps, stride = meta["size"], meta["steps"], meta["lattice_stride"]
+    parts = _run_ranks(world, "iso3dfd", g, nr, steps, opts, transport, stride)
+    for rank, f, l, _, _, info in parts:
+        print(f"rank {rank} box {f}..{l}: {info}")
+        assert info["msgs"] > 0
+    one = _one_rank_cached("iso3dfd", g, steps)
+    _check_against_one_rank_and_reference(parts, one, "iso3dfd", g, steps, stride, G / "c2_iso3dfd_1024_s2_lattice.npz", True)
+
+
+def test_ssg_512_one_rank_matches_reference_lattice_and_oracle_and_eight_ranks_match_it(gpu):
+    meta = INDEX["c5_ssg_512_s3_lattice"]
+    g, steps, stride = meta["size"], meta["steps"], meta["lattice_stride"]
+    one = _one_rank_cached("ssg", g, steps)
+    print("ssg 512^3 kernels:", [one.get_kernel_variant(p) for p in range(one.get_num_parts())])
+    # (a) one rank vs the reference's lattice and the C oracle at every point
+    z = np.load(G / "c5_ssg_512_s3_lattice.npz")
+    ref = O.run_ssg(tuple(g), steps)
+    lat = [O.lattice(s, stride) for s in g]
+    for f in O.SSG_FIELDS:
+        var = one.get_var(f)
+        worst, big = 0.0, 0.0
+        got_l = []
+        for x0 in range(0, g[0], 64):
+            a = var.get_elements_in_slice([steps, x0, 0, 0], [steps, x0 + 63, g[1] - 1, g[2] - 1])[0]
+            r = ref[(f, steps)][x0:x0 + 64]
+            worst = max(worst, float(np.abs(a - r).max()))
+            big = max(big, float(np.abs(r).max()))
+            for x in lat[0][(lat[0] >= x0) & (lat[0] < x0 + 64)]:
+                got_l.append(a[int(x) - x0][np.ix_(lat[1], lat[2])])
+        assert worst / big <= 2e-5, (f, "whole box vs oracle", worst, big)
+        ref_l = z[f"{f}@{steps}"].astype(np.float64)
+        err = np.abs(np.stack(got_l).astype(np.float64) - ref_l).max() / np.abs(ref_l).max()
+        assert err <= 2e-5, (f, "lattice vs reference", err)
+    del ref
+    # (b) eight 256^3 blocks (2x2x2) vs that run, bit for bit, and vs the reference lattice
+    parts = _run_ranks(8, "ssg", g, (2, 2, 2), steps, "", "ipc", stride)
+    for rank, f, l, _, _, info in parts:
+        print(f"rank {rank} box {f}..{l}: {info}")
+    _check_against_one_rank_and_reference(parts, one, "ssg", g, steps, stride, G / "c5_ssg_512_s3_lattice.npz", False)
+    for k in list(_ONE):
+        _ONE.pop(k).end_solution()

@@ -113,7 +113,7 @@ def _init(soln, stencil):
 
 def _tcp_worker(rank, world, port, q, mode, stencil, g, nr, steps):
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      YASK_HIP_TRANSPORT="tcp")
+                      YASK_HIP_TRANSPORT=os.environ.get("YASK_TEST_TRANSPORT", "tcp"))
     from yask_amd import yk_factory
     fac = yk_factory(stencil)
     env = fac.new_env()
@@ -198,8 +198,12 @@ def _assemble(parts, stencil, g):
     return full
 
 
+@pytest.mark.parametrize("transport", ["tcp", "ipc"])
 @pytest.mark.parametrize("mode", ["x", "z"])
-def test_native_bootstrap_tcp_two_ranks_equal_one_rank(gpu, mode):
+def test_native_bootstrap_two_ranks_equal_one_rank(gpu, mode, transport, monkeypatch):
+    """Two processes, one GPU, no torch: the host-staged TCP transport and the device-to-device IPC transport (HIP IPC
+    handles, copies into the neighbour's buffer, stream-ordered flag words: yask_amd/csrc/ykh_ipc.cpp)."""
+    monkeypatch.setenv("YASK_TEST_TRANSPORT", transport)
     g, steps = (48, 40, 72), 4
     parts = _run_ranks(2, mode, nr=(2, 1, 1) if mode == "x" else (1, 1, 2))
     full = _assemble(parts, "iso3dfd", g)["p"]
@@ -214,27 +218,39 @@ def test_native_bootstrap_tcp_two_ranks_equal_one_rank(gpu, mode):
         else:
             assert s["sent"] == (steps + 2) * face and s["recv"] == s["sent"]
         assert steps + 1 <= s["msgs"] <= steps + 2
-        assert s["xfer"] > 0 and s["inter"] > 0 and s["ext"] > 0 and s["wait"] >= 0
+        # (planned launches: "exterior" ends when the comm stream has seen the shell blocks' signal, which on a grid this small
+        #  may be after the launch itself has ended -- the interior span is then zero)
+        assert s["xfer"] > 0 and s["inter"] >= 0 and s["ext"] > 0 and s["wait"] >= 0
         assert s["halo"] >= s["pack"] + s["xfer"] + s["unpack"] - 1e-9
         assert s["hidden"] is not None and 0.0 <= s["hidden"] <= 1.0
 
 
-def test_exchange_halos_after_a_change_on_one_rank_only(gpu):
+@pytest.mark.parametrize("transport", ["tcp", "ipc"])
+def test_exchange_halos_after_a_change_on_one_rank_only(gpu, transport, monkeypatch):
     """rank 0 alone marks a var dirty; all ranks call exchange_halos().  Every rank must post the same
     messages (the reference's set_all_neighbor_vars_dirty, context.cpp:234) -- this used to hang / mismatch."""
+    monkeypatch.setenv("YASK_TEST_TRANSPORT", transport)
     parts = dict((r, v) for r, v in _run_ranks(2, "one_sided"))
     assert parts[1] == 123.5
 
 
-@pytest.mark.parametrize("ext_streams", [0, 1, 2])
-@pytest.mark.parametrize("stencil,g,steps", [("iso3dfd", (48, 40, 72), 3), ("ssg", (32, 28, 40), 2)])
-def test_eight_ranks_on_the_compact_2x2x2_grid(gpu, stencil, g, steps, ext_streams, monkeypatch):
+SCHEDULES = {"planned": "", "planned_greedy": "-hip_plan_mode 1 -hip_shell_pct 30", "planned_uniform_ipc": "-hip_plan_mode 2",
+             "slabs0": "-no-hip_planned_launch -hip_ext_streams 0", "slabs1": "-no-hip_planned_launch -hip_ext_streams 1",
+             "slabs2": "-no-hip_planned_launch -hip_ext_streams 2"}
+
+
+@pytest.mark.parametrize("stencil,g,steps,sched", [("iso3dfd", (48, 40, 72), 3, k) for k in SCHEDULES] +
+                         [("ssg", (32, 28, 40), 2, k) for k in ("planned", "planned_greedy", "slabs0")])
+def test_eight_ranks_on_the_compact_2x2x2_grid(gpu, stencil, g, steps, sched, monkeypatch):
     """BASELINE.json configs[3]/[4] run on the reference's default rank grid for 8 ranks, 2x2x2
     (get_compact_factors, src/common/tuple.cpp:355-430): 3 face neighbours per rank for iso3dfd; ssg's `mu` is read
     diagonally (L1 norm 2), so its halos also travel to the 3 edge neighbours.  Eight processes share the GPU (TCP
-    transport); the assembled result equals the 1-rank run bit for bit -- with the three exterior slabs of a rank issued one
-    after another (-hip_ext_streams 0, the default), side by side on their own streams (1) and beside the interior (2)."""
-    monkeypatch.setenv("YASK_TEST_EXTRA_OPTS", f"-hip_ext_streams {ext_streams}")
+    or IPC transport); the assembled result equals the 1-rank run bit for bit -- as ONE planned launch per stage (shell blocks
+    first, the exchange released from the device; the default, here with the planner's automatic, greedy and uniform interior
+    pieces) and as round 2's separate launches: exterior slabs one after another (-hip_ext_streams 0), side by side on their own
+    streams (1) and beside the interior (2)."""
+    monkeypatch.setenv("YASK_TEST_EXTRA_OPTS", SCHEDULES[sched])
+    monkeypatch.setenv("YASK_TEST_TRANSPORT", "ipc" if sched.endswith("_ipc") or sched == "planned" else "tcp")
     parts = _run_ranks(8, "run", stencil=stencil, g=g, nr=None, steps=steps)
     assert all(s["grid"] == [2, 2, 2] for _, _, _, s in parts)
     full = _assemble(parts, stencil, g)
@@ -247,10 +263,12 @@ def test_eight_ranks_on_the_compact_2x2x2_grid(gpu, stencil, g, steps, ext_strea
         assert np.abs(full[n].astype(np.float64) - r).max() / max(1.0 if stencil == "iso3dfd" else 1e-30, np.abs(r).max()) <= 2e-5, n
 
 
+@pytest.mark.parametrize("transport", ["tcp", "ipc"])
 @pytest.mark.parametrize("nr,g", [((4, 1, 1), (64, 24, 40)), ((2, 2, 1), (40, 48, 40)), ((1, 2, 2), (24, 40, 72))])
-def test_four_ranks_slab_and_pencil_grids(gpu, nr, g):
+def test_four_ranks_slab_and_pencil_grids(gpu, nr, g, transport, monkeypatch):
     """Four ranks: x-slabs (the two middle ranks have an in-place x-face transfer on both sides), and the 2x2x1 / 1x2x2
     grids (one direct and one packed face per rank; 1x2x2: packed faces only, thin y/z exteriors)."""
+    monkeypatch.setenv("YASK_TEST_TRANSPORT", transport)
     steps = 3
     parts = _run_ranks(4, "run", stencil="iso3dfd", g=g, nr=nr, steps=steps)
     assert all(s["grid"] == list(nr) for _, _, _, s in parts)

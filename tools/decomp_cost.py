@@ -2,9 +2,12 @@
 """GPU box (one GPU): what does the exterior-first schedule of a decomposed run cost on the compute side?
 
 For the local block a rank gets in bench.py's scaling configurations, replays the launches Solution::run() issues for
-one step -- exterior slabs (thin ones on the point kernel, the z exterior one marching tile wide), then the interior in
--hip_overlap_splits pieces -- with no communication, and compares with the undivided box (yk_solution_time_decomposed_step).
-    python tools/decomp_cost.py [--stencil iso3dfd]"""
+one step, with no communication, and compares with the undivided box (yk_solution_time_decomposed_step):
+  * planned launches (round 3, the default): ONE launch of the marching kernel over the rank box, shell blocks first; `shell_ms`
+    = until the device-side signal that releases the halo exchange, `rest_ms` = from there to the end of the launch;
+  * round 2's separate launches (-no-hip_planned_launch): exterior slabs (thin ones on the point kernel, the z exterior one
+    marching tile wide), then the interior in -hip_overlap_splits pieces.
+    python tools/decomp_cost.py [--stencil iso3dfd] [--quick]"""
 import argparse
 import json
 import sys
@@ -14,41 +17,61 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 
 CASES = [  # name, local size, neighbours on the (lo, hi) side of x, y, z
     ("c2 / 8 GPUs, 2x2x2, local 512^3 (corner rank: one neighbour per dim)", (512, 512, 512), (0, 0, 0), (1, 1, 1)),
+    ("c4 / 8 GPUs, 2x2x2, local 1024x1024x512", (1024, 1024, 512), (0, 0, 0), (1, 1, 1)),
     ("c2 / 4 GPUs, 2x2x1, local 512x512x1024", (512, 512, 1024), (0, 0, 0), (1, 1, 0)),
     ("c2 / 2 GPUs, 2x1x1, local 512x1024x1024", (512, 1024, 1024), (0, 0, 0), (1, 0, 0)),
     ("c2 / 8 GPUs as x-slabs, middle rank, local 128x1024x1024", (128, 1024, 1024), (1, 0, 0), (1, 0, 0)),
-    ("c4 / 8 GPUs, 2x2x2, local 1024x1024x512", (1024, 1024, 512), (0, 0, 0), (1, 1, 1)),
+]
+SSG_CASES = [
+    ("ssg 512^3 global / 8 GPUs, 2x2x2, local 256^3", (256, 256, 256), (0, 0, 0), (1, 1, 1)),
+    ("ssg 1024^3 global / 8 GPUs, 2x2x2, local 512^3", (512, 512, 512), (0, 0, 0), (1, 1, 1)),
+]
+CONFIGS = [  # label, options
+    ("planned pct45 auto", "-hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 0"),
+    ("planned pct45 greedy", "-hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 1"),
+    ("planned pct45 uniform", "-hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 2"),
+    ("planned pct30 greedy", "-hip_planned_launch -hip_shell_pct 30 -hip_plan_mode 1"),
+    ("planned pct65 greedy", "-hip_planned_launch -hip_shell_pct 65 -hip_plan_mode 1"),
+    ("planned pct80 greedy", "-hip_planned_launch -hip_shell_pct 80 -hip_plan_mode 1"),
+    ("slabs, interior in 2 launches (round 2 default)", "-no-hip_planned_launch -hip_overlap_splits 2"),
+    ("slabs, interior in 1 launch", "-no-hip_planned_launch -hip_overlap_splits 1"),
 ]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stencil", default="iso3dfd")
-    ap.add_argument("--splits", type=int, nargs="+", default=[2, 1])
-    ap.add_argument("--ext-modes", type=int, nargs="+", default=[0, 1, 2], help="-hip_ext_streams values to compare")
+    ap.add_argument("--quick", action="store_true", help="the two BASELINE blocks, three configurations")
+    ap.add_argument("--reps", type=int, default=8)
     args = ap.parse_args()
     from yask_amd import yk_factory
     from yask_amd.kernel import yk_env
     yk_env.disable_debug_output()
     fac = yk_factory(args.stencil)
+    cases = SSG_CASES if args.stencil == "ssg" else CASES
+    configs = CONFIGS
+    if args.quick:
+        cases, configs = cases[:2], [CONFIGS[0], CONFIGS[1], CONFIGS[6]]
     out = []
-    for name, size, lo, hi in CASES:
-        for sp, em in [(a, b) for a in args.splits for b in args.ext_modes]:
+    for name, size, lo, hi in cases:
+        for label, opts in configs:
             s = fac.new_solution(fac.new_env())
             s.set_overall_domain_size_vec(list(size))
-            s.apply_command_line_options(f"-no-auto_tune -hip_overlap_splits {sp} -hip_ext_streams {em}")
+            assert s.apply_command_line_options("-no-auto_tune " + opts) == ""
             s.prepare_solution()
             for k, v in enumerate(s.get_vars()):
                 v.set_elements_hash(1.0, 0.1, hash_id=k)
-            ext, inter, whole = s.time_decomposed_step(lo, hi, reps=5)
+            ext, inter, whole = s.time_decomposed_step(lo, hi, reps=args.reps)
             pts = size[0] * size[1] * size[2]
-            rec = {"case": name, "splits": sp, "ext_streams": em, "exterior_ms": round(ext, 4), "interior_ms": round(inter, 4), "whole_ms": round(whole, 4),
-                   "overhead": round((ext + inter) / whole, 3), "gpoints_per_s_split": round(pts / (ext + inter) * 1e-6, 1),
-                   "gpoints_per_s_whole": round(pts / whole * 1e-6, 1)}
+            rec = {"case": name, "config": label, "shell_or_exterior_ms": round(ext, 4), "rest_or_interior_ms": round(inter, 4), "undivided_ms": round(whole, 4),
+                   "overhead": round((ext + inter) / whole, 3), "shell_done_at_fraction": round(ext / (ext + inter), 3),
+                   "gpoints_per_s_decomposed": round(pts / (ext + inter) * 1e-6, 1), "gpoints_per_s_undivided": round(pts / whole * 1e-6, 1)}
             out.append(rec)
             print(json.dumps(rec), flush=True)
             s.end_solution()
-    json.dump(out, open(Path(__file__).resolve().parents[1] / "gpurun_out" / f"decomp_cost_{args.stencil}.json", "w"), indent=1)
+    od = Path(__file__).resolve().parents[1] / "gpurun_out"
+    od.mkdir(exist_ok=True)
+    json.dump(out, open(od / f"decomp_cost_{args.stencil}.json", "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -46,6 +46,10 @@ _S = C.c_char_p
 _IP = C.POINTER(idx_t)
 
 # name -> (restype, argtypes); kept in the same order as the header.
+class BlockDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("x0", "x1", "y0", "y1", "z0", "z1", "flags", "start")]
+
+
 class RankPlan(C.Structure):
     """yk_rank_plan_t"""
     _fields_ = [("global_size", idx_t * 3), ("local_size", idx_t * 3), ("num_ranks", idx_t * 3), ("rank_index", idx_t * 3),
@@ -66,6 +70,7 @@ PROTOTYPES = {
     "yk_solution_get_placement_trials": (C.c_int, [_H, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int]),
     "yk_env_init_from_launcher": (C.c_int, [_H]),
     "yk_env_init_tcp": (C.c_int, [_H, C.c_int, C.c_int, _S, C.c_int]),
+    "yk_env_init_ipc": (C.c_int, [_H, C.c_int, C.c_int, _S, C.c_int]),
     "yk_rendezvous_bcast": (C.c_int, [C.c_int, C.c_int, _S, C.c_int, C.c_void_p, C.c_size_t]),
     "yk_tcp_mesh_check": (C.c_int, [C.c_int, C.c_int, _S, C.c_int, C.POINTER(C.c_longlong)]),
     "yk_env_transport_loopback": (C.c_int, [_H, C.c_size_t]),
@@ -77,6 +82,8 @@ PROTOTYPES = {
     "yk_var_set_elements_in_slice_from_var": (idx_t, [_H, _H, C.POINTER(idx_t), C.POINTER(idx_t), C.POINTER(idx_t)]),
     "yk_plan_wavefront": (C.c_int, [idx_t, idx_t, idx_t, idx_t, idx_t, C.POINTER(idx_t), C.c_int]),
     "yk_plan_rank": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(RankPlan)]),
+    "yk_plan_blocks": (C.c_int, [C.POINTER(idx_t), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(idx_t), C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.POINTER(BlockDesc), C.c_int, C.POINTER(idx_t)]),
     "yk_plan_halo_slab": (C.c_int, [C.c_int, C.POINTER(RankPlan), C.POINTER(C.c_int), C.POINTER(idx_t), C.POINTER(idx_t),
                                     C.c_int, C.c_int, C.POINTER(Box)]),
     "yk_last_error": (_S, []),

@@ -526,6 +526,22 @@ int yk_plan_wavefront(yk_idx_t lo, yk_idx_t hi, yk_idx_t width, yk_idx_t angle, 
     YK_CATCH(-1)
 }
 
+int yk_plan_blocks(const yk_idx_t* n3, const int* has_lo3, const int* has_hi3, const yk_idx_t* width3, int tile_y, int tile_z,
+                   int overhead, int num_cus, int shell_pct, int mode, yk_block_desc_t* out, int cap, yk_idx_t* info5) {
+    YK_TRY
+    if (!n3 || !has_lo3 || !has_hi3 || !width3) YKH_THROW("yk_plan_blocks: null argument");
+    BlockPlanIn in;
+    for (int d = 0; d < 3; d++) { in.n[d] = n3[d]; in.has_lo[d] = has_lo3[d] != 0; in.has_hi[d] = has_hi3[d] != 0; in.width[d] = width3[d]; }
+    in.ty = tile_y; in.tz = tile_z; in.overhead = overhead; in.ncu = num_cus; in.shell_frac = shell_pct / 100.0; in.mode = mode;
+    BlockPlan p;
+    try { p = plan_blocks(in); } catch (const PlanError& e) { YKH_THROW(e.what()); }
+    static_assert(sizeof(yk_block_desc_t) == sizeof(BlockDesc), "yk_block_desc_t mirrors ykh::BlockDesc");
+    for (int i = 0; i < (int)p.blocks.size() && i < cap && out; i++) std::memcpy(&out[i], &p.blocks[i], sizeof(BlockDesc));
+    if (info5) { info5[0] = p.n_signal; info5[1] = p.shell_done; info5[2] = p.makespan; info5[3] = p.undivided; info5[4] = p.mode_used; }
+    return (int)p.blocks.size();
+    YK_CATCH(-1)
+}
+
 // ---- var
 const char* yk_var_get_name(yk_var_h v) { return v ? reinterpret_cast<Var*>(v)->name.c_str() : ""; }
 int yk_var_get_num_dims(yk_var_h v) { return v ? (int)reinterpret_cast<Var*>(v)->dims.size() : 0; }

@@ -75,7 +75,62 @@ struct PartArgs {
     int dom_x1, dom_y1, dom_z1;   // the rank's domain is [0, dom_*1) in local indices (the box x0..z1 may be a part of it)
     int lane_dim;                 // point kernels: domain dim the 64 lanes of a wave run along = the solution's innermost
                                   // (unit-stride) domain dim: 2 for x,y,z solutions, 1 for 2-D, 0 for 1-D ones
+    // planned launches of a decomposed rank (ykh_plan.cpp plan_blocks, Solution::launch_planned): workgroup i marches blk[i]
+    const BlockDesc* blk;         // null: the regular tiling of the box x0..z1
+    unsigned* sig;                // [0] running count of finished signalling blocks, [1] published epoch, [2] waiter's error flag
+    unsigned sig_goal;            // the block that raises sig[0] to this value publishes ...
+    unsigned sig_epoch;           // ... this epoch in sig[1]: the comm stream's wait_epoch_kernel then lets the halo exchange start
 };
+
+// The (y, z) tile and x range of the calling workgroup of a marching kernel, and the box its stores are clipped to.
+struct BlockBox { int xs, xe, yt0, y1, zt0, z0, z1, flags; };
+template <int VZ, int TZ, int TY>
+__device__ __forceinline__ BlockBox block_box(const PartArgs& a) {
+    BlockBox b;
+    if (a.blk) {
+        // planned launch: everything comes from the descriptor (uniform: kept in SGPRs)
+        const BlockDesc* d = a.blk + blockIdx.x;
+        b.xs = __builtin_amdgcn_readfirstlane(d->x0); b.xe = __builtin_amdgcn_readfirstlane(d->x1);
+        b.yt0 = __builtin_amdgcn_readfirstlane(d->y0); b.y1 = __builtin_amdgcn_readfirstlane(d->y1);
+        b.z0 = __builtin_amdgcn_readfirstlane(d->z0); b.z1 = __builtin_amdgcn_readfirstlane(d->z1);
+        b.flags = __builtin_amdgcn_readfirstlane(d->flags);
+        b.zt0 = b.z0 & ~(VZ - 1);
+        return b;
+    }
+    // XCD-aware tile assignment: block i runs on XCD i % 8; each XCD owns a contiguous range of (y,z) tiles, so that
+    // neighbouring tiles share one L2
+    const int ntiles = a.ntz * a.nty * a.nxc;
+    int bid = blockIdx.x;
+    if ((ntiles & 7) == 0) bid = (bid & 7) * (ntiles >> 3) + (bid >> 3);
+    const int tz_i = bid % a.ntz;
+    const int ty_i = (bid / a.ntz) % a.nty;
+    const int xc_i = bid / (a.ntz * a.nty);
+    b.zt0 = (a.z0 & ~(VZ - 1)) + tz_i * TZ;
+    b.yt0 = a.y0 + ty_i * TY;
+    b.xs = a.x0 + xc_i * a.xchunk;
+    b.xe = (b.xs + a.xchunk < a.x1) ? b.xs + a.xchunk : a.x1;
+    b.y1 = a.y1; b.z0 = a.z0; b.z1 = a.z1; b.flags = 0;
+    return b;
+}
+// End of a signalling block of a planned launch: its stores are made visible (system scope: the next reader may be a copy
+// engine or a peer), then it counts itself done; the block that completes the count publishes the launch's epoch.
+// Recipe of MI355X_MICROARCH.md "hand-off": stores -> barrier -> ONE lane: release fence -> s_waitcnt -> flag.
+__device__ __forceinline__ void block_done(const PartArgs& a, int flags) {
+    if (!(flags & BLOCK_SIGNALS) || !a.sig) return;          // (uniform)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned old = __hip_atomic_fetch_add(a.sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == a.sig_goal) {
+            // every other signalling block released its data before its increment, which this thread has observed
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(a.sig + 1, a.sig_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 // point-kernel thread -> (x, y, z): lanes along `lane_dim`, 4 rows per block along the next outer dim, blockIdx.z
 // over what is left.  With fewer than 3 domain dims the missing ones have extent 1 (a 2-D solution used to put its 64
 // lanes on that size-1 z: 4 active lanes per 256-thread block and fully uncoalesced rows).

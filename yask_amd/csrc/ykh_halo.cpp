@@ -70,6 +70,7 @@ void Solution::alloc_halo_buffers() {
 }
 
 void Solution::free_halo_buffers() {
+    if (env && env->exch_reset && !xfers.empty()) env->exch_reset(env->user);       // (a transport may hold mappings of these buffers)
     for (auto& x : xfers) {
         if (x->send_buf) (void)hipFree(x->send_buf);
         if (x->recv_buf) (void)hipFree(x->recv_buf);
@@ -122,10 +123,21 @@ void Solution::exchange_halos(idx_t /*t_written*/, int /*stage*/, bool start_onl
         for (auto& v : vars)
             for (char d : v->dirty) any |= (d != 0);
         msgs.clear();
+        const bool signalled = sig_pending;
+        sig_pending = false;
         if (!any) return;
-        // comm stream waits for the kernels that produced the data
-        YKH_HIP(hipEventRecord(ev_a, compute_stream));
-        YKH_HIP(hipStreamWaitEvent(comm_stream, ev_a, 0));
+        if (signalled) {
+            // planned launch: the data the neighbours need comes from the launch's shell blocks, which publish an epoch when the
+            // last of them has finished (block_done(), ykh_device.hpp) -- the comm stream waits for THAT, not for the launch
+            const unsigned* wp = sig_dev + 1;
+            const unsigned wv = sig_epoch;
+            launch_wait_words(1, &wp, &wv, sig_dev + 2, 20.0, comm_stream);
+            phase_mark(PH_EXT1, comm_stream);         // = the exterior is done (interior_secs then runs from here to PH_INT1)
+        } else {
+            // comm stream waits for the kernels that produced the data
+            YKH_HIP(hipEventRecord(ev_a, compute_stream));
+            YKH_HIP(hipStreamWaitEvent(comm_stream, ev_a, 0));
+        }
         phase_mark(PH_PACK0, comm_stream);
         for (auto& x : xfers) {
             if (x->direct) {

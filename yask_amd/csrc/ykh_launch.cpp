@@ -27,9 +27,10 @@
 
 #include "../../include/yask_hip_c_api.h"
 #include "ykh_handles.hpp"
+#include "ykh_mesh.hpp"
 #include "ykh_runtime.hpp"
 
-namespace {
+namespace ykh_mesh {
 
 bool send_all(int fd, const void* p, size_t n) {
     const char* c = (const char*)p;
@@ -103,14 +104,11 @@ int env_int(const char* const* names, int dflt) {
     return dflt;
 }
 
+}  // namespace ykh_mesh
+using namespace ykh_mesh;
+
+namespace {
 // ---------------------------------------------------------------- host-staged TCP transport (tests / one-GPU jobs)
-struct TcpState {
-    int rank = 0, nranks = 1;
-    std::vector<int> fd;                 // one connected socket per peer (-1 for self)
-    std::vector<std::vector<char>> rstage;   // per message receive staging (kept until wait)
-    std::vector<void*> rdst;
-    std::vector<size_t> rbytes;
-};
 struct MsgHdr { int tag; unsigned long long bytes; };
 
 // All sends and receives of one exchange progress together (poll loop): both ends of a link send large
@@ -196,6 +194,8 @@ int tcp_wait(void* user, int n, const ykh::HaloMsg*, void* stream) {
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 1;       // staging buffers are reused
     return 0;
 }
+}  // namespace
+namespace ykh_mesh {
 int tcp_allreduce(void* user, int op, long long* val) {
     TcpState* st = static_cast<TcpState*>(user);
     if (st->nranks <= 1) return 0;
@@ -302,7 +302,7 @@ TcpState* tcp_connect_mesh(int rank, int nranks, const char* addr, int base_port
     return st;
 }
 
-}  // namespace
+}  // namespace ykh_mesh
 
 extern "C" {
 
@@ -384,6 +384,7 @@ int yk_env_init_from_launcher(yk_env_h e) {
         const int port = env_int(port_v, 29533);
         const char* tr = getenv("YASK_HIP_TRANSPORT");
         if (tr && std::strcmp(tr, "tcp") == 0) return yk_env_init_tcp(e, rank, nranks, addr, port + 16);
+        if (tr && std::strcmp(tr, "ipc") == 0) return yk_env_init_ipc(e, rank, nranks, addr, port + 16);
         unsigned char id[128] = {0};
         if (rank == 0 && yk_rccl_get_unique_id(id) != 0) { fprintf(stderr, "yask: ncclGetUniqueId failed\n"); return 1; }
         if (yk_rendezvous_bcast(rank, nranks, addr, port + 1, id, sizeof(id)) != 0) return 1;

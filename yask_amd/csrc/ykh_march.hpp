@@ -130,6 +130,10 @@ struct MarchCfg {
     static constexpr int NMIX = tab.nmix;
     static constexpr int RING_TOT = tab.roff[NG];           // elements of the halo rings
     static constexpr size_t lds_bytes = sizeof(T) * (2 * (SLAB_TOT > 0 ? SLAB_TOT : 1) + RING_TOT);
+    // what a block pays before its first plane, in plane-iterations (the cost model of planned launches, ykh_plan.cpp): its
+    // deepest queue is filled with own-point loads only -- about half the work of a plane per queue plane
+    static constexpr int max_nq() { int m = 1; for (int g = 0; g < NG; g++) if (tab.nq[g] > m) m = tab.nq[g]; return m; }
+    static constexpr int XOVER = (max_nq() + 1) / 2 + 1;
 };
 
 // PIN: honour the generated code's pin() after every temporary (strict program order: smallest live
@@ -254,18 +258,11 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
     T* slab = reinterpret_cast<T*>(ykh_smem);
     T* ring = slab + 2 * (C::SLAB_TOT > 0 ? C::SLAB_TOT : 1);
 
-    const int ntiles = a.ntz * a.nty * a.nxc;
-    int bid = blockIdx.x;
-    if ((ntiles & 7) == 0) bid = (bid & 7) * (ntiles >> 3) + (bid >> 3);
-    const int tz_i = bid % a.ntz;
-    const int ty_i = (bid / a.ntz) % a.nty;
-    const int xc_i = bid / (a.ntz * a.nty);
+    const BlockBox bb = block_box<VZ, C::TZ, C::TY>(a);      // regular tiling of the box, or a planned launch's descriptor
     const int tid = threadIdx.x;
     const int lz = tid % TZL, ly = tid / TZL;
-    const int zt0 = (a.z0 & ~(VZ - 1)) + tz_i * C::TZ;
-    const int yt0 = a.y0 + ty_i * C::TY;
-    const int xs = a.x0 + xc_i * a.xchunk;
-    const int xe = (xs + a.xchunk < a.x1) ? xs + a.xchunk : a.x1;
+    const int zt0 = bb.zt0, yt0 = bb.yt0, xs = bb.xs, xe = bb.xe;
+    const int bz0 = bb.z0, bz1 = bb.z1, by1 = bb.y1;           // the box the stores are clipped to
     if (xs >= xe) return;
     const int myz = zt0 + lz * VZ;
     const int myy0 = yt0 + ly * RY;       // first of this thread's RY rows
@@ -467,10 +464,10 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
             V out[MAX_GROUPS];
             MarchAcc<C, P, PIN, OPS, PH, LO> acc{a, q[j], mreg[S][j], nxt[S][j], sb, ly * RY + j, lz, x, myy, myz, out, m1};
             P::eval(acc);
-            if (x < xe && myy < a.y1 && myz < a.z1 && myz + VZ > a.z0) {
+            if (x < xe && myy < by1 && myz < bz1 && myz + VZ > bz0) {
                 // (written groups are vars over all dims; the store predicate implies yc[j] == myy, zc == myz)
                 const idx_t xo = org + (idx_t)x * a.sx;
-                const bool whole = myz >= a.z0 && myz + VZ <= a.z1;
+                const bool whole = myz >= bz0 && myz + VZ <= bz1;
                 static_for<P::n_writes>([&](auto wc) {
                     constexpr int g = P::writes[decltype(wc)::value];
                     auto ob = sbase((T*)a.ptr[g] + xo);
@@ -478,7 +475,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
                     else
                         static_for<VZ>([&](auto ec) {
                             constexpr int e = decltype(ec)::value;
-                            if (myz + e >= a.z0 && myz + e < a.z1) stv_b<T>(ob, ooff[j] + e * (unsigned)sizeof(T), out[g][e]);
+                            if (myz + e >= bz0 && myz + e < bz1) stv_b<T>(ob, ooff[j] + e * (unsigned)sizeof(T), out[g][e]);
                         });
                 });
             }
@@ -521,6 +518,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
             });
         }
     }
+    block_done(a, bb.flags);
 }
 
 }  // namespace ykh

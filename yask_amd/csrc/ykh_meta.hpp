@@ -83,6 +83,17 @@ struct PartMeta {
                                                    // such solutions are not replayed from a captured step graph)
 };
 
+// One workgroup of a *planned launch* (ykh_plan.cpp `plan_blocks`, Solution::launch_planned): the (y, z) tile the block owns,
+// clipped to the rank box, and the x range it marches.  flags bit 0: the block counts towards the launch's completion signal
+// (its output is needed by a neighbour rank: the halo exchange starts when all such blocks have finished, while the rest of the
+// launch is still running).
+struct BlockDesc {
+    int x0, x1, y0, y1, z0, z1;
+    int flags;
+    int start;       // planned start time, in plane-iterations from the beginning of the launch (planner's estimate; not read on the device)
+};
+enum { BLOCK_SIGNALS = 1 };
+
 struct StageMeta {
     const char* name;
     int n_parts;

@@ -183,4 +183,177 @@ std::vector<WavefrontLaunch> plan_wavefront(idx_t lo, idx_t hi, idx_t width, idx
     return out;
 }
 
+// ------------------------------------------------------------------ planned launch of a decomposed rank
+// The reference computes the exterior of a rank first, starts the halo exchange, and computes the interior while the messages
+// travel (StencilContext::run_solution, src/kernel/lib/context.cpp:377-478; `-min_exterior`, settings.hpp:245).  Round 2 did
+// that with separate launches -- slabs, then the interior in pieces -- and paid 1.2-1.5x the undivided sweep on a 512^3 block:
+// thin slabs leave CUs idle or fall back to the point kernel, every launch boundary drains the chip, every interior piece
+// re-runs the marching kernel's prologue.  Here the whole rank box is ONE launch of the marching kernel whose workgroups are
+// handed (tile, x-range) descriptors in a planned order:
+//   1. x-face shell: for every (y, z) tile the `width` planes next to an x neighbour (thin blocks);
+//   2. y/z shell: the tiles that touch a y or z face with a neighbour -- WHOLE tiles of the regular tiling, so they cost what
+//      they cost in an undivided sweep -- cut into x-chunks short enough to finish after ~shell_frac of the launch;
+//   3. the interior tiles, in x-pieces sized so that every CU finishes at the same time: CUs that were idle from the start
+//      get long pieces, CUs that first ran shell blocks get the rest (list scheduling against the simulated CU time line).
+// Blocks are dispatched in index order, so the shell runs first and the interior backfills; shell blocks count themselves
+// done on the device and the last one releases the exchange (Solution::launch_planned).  Same kernel, same per-point
+// arithmetic as a one-rank sweep: results are bit-identical whatever the plan.
+namespace {
+struct CuLine {          // availability times of the CUs; blocks go to the CU that frees first (the hardware's own rule)
+    std::vector<idx_t> t;
+    explicit CuLine(idx_t n) : t((size_t)n, 0) {}
+    size_t earliest() const { return (size_t)(std::min_element(t.begin(), t.end()) - t.begin()); }
+    idx_t run(idx_t len) { const size_t c = earliest(); const idx_t s = t[c]; t[c] = s + len; return s; }
+    idx_t makespan() const { return *std::max_element(t.begin(), t.end()); }
+};
+struct TileBox { idx_t y0, y1, z0, z1; };
+// blocks go round-robin over 8 strips of the tile-ordered list: block i of a launch runs on XCD i % 8, so each XCD's L2
+// serves a contiguous strip of neighbouring tiles (the regular launches' mapping, ykh_starlin.hpp)
+template <class T>
+std::vector<T> deal_over_xcds(const std::vector<T>& v) {
+    const size_t n = v.size();
+    if (n < 16) return v;
+    std::vector<T> out;
+    out.reserve(n);
+    size_t lo[9];
+    for (int k = 0; k <= 8; k++) lo[k] = n * (size_t)k / 8;
+    for (size_t r = 0; out.size() < n; r++)
+        for (int k = 0; k < 8; k++)
+            if (lo[k] + r < lo[k + 1]) out.push_back(v[lo[k] + r]);
+    return out;
+}
+}  // namespace
+
+BlockPlan plan_blocks(const BlockPlanIn& in) {
+    BlockPlan out;
+    const idx_t nx = in.n[0], ny = in.n[1], nz = in.n[2];
+    if (nx < 1 || ny < 1 || nz < 1 || in.ty < 1 || in.tz < 1 || in.ncu < 1) throw PlanError("plan_blocks: bad box or tile");
+    const idx_t o = std::max<idx_t>(0, in.overhead), minlen = std::max<idx_t>(1, in.min_len);
+    auto desc = [](const TileBox& tb, idx_t x0, idx_t x1, int flags, idx_t start) {
+        BlockDesc d;
+        d.x0 = (int)x0; d.x1 = (int)x1; d.y0 = (int)tb.y0; d.y1 = (int)tb.y1; d.z0 = (int)tb.z0; d.z1 = (int)tb.z1;
+        d.flags = flags; d.start = (int)start;
+        return d;
+    };
+    // ---- tiles of the regular tiling; shell tiles = those a y / z neighbour needs something of
+    std::vector<TileBox> shell_t, inner_t, all_t;
+    auto touches = [&](idx_t a, idx_t b, idx_t n, int d) {       // does [a, b) reach into the boundary strips of dim d?
+        const idx_t w = std::max<idx_t>(1, in.width[d]);
+        return (in.has_lo[d] && a < w) || (in.has_hi[d] && b > n - w);
+    };
+    for (idx_t y0 = 0; y0 < ny; y0 += in.ty)
+        for (idx_t z0 = 0; z0 < nz; z0 += in.tz) {
+            TileBox tb{y0, std::min(y0 + in.ty, ny), z0, std::min(z0 + in.tz, nz)};
+            all_t.push_back(tb);
+            (touches(tb.y0, tb.y1, ny, 1) || touches(tb.z0, tb.z1, nz, 2) ? shell_t : inner_t).push_back(tb);
+        }
+    // ---- x: thin shell slabs next to x neighbours, the main range between them
+    idx_t xa = 0, xb = nx;
+    const idx_t wx = std::max<idx_t>(1, in.width[0]);
+    if (in.has_lo[0]) xa = std::min(wx, nx);
+    if (in.has_hi[0]) xb = std::max(xa, nx - wx);
+    const idx_t nmain = xb - xa;
+    // ---- the undivided box as ONE regular launch, for reference: tiles x k uniform chunks, best k
+    {
+        idx_t best = -1;
+        for (idx_t k = 1; k <= 64; k++) {
+            const idx_t len = (nx + k - 1) / k;
+            if (k > 1 && len < 32) break;
+            CuLine cl(in.ncu);
+            for (idx_t c = 0; c * len < nx; c++)
+                for (size_t i = 0; i < all_t.size(); i++) cl.run(std::min(len, nx - c * len) + o);
+            if (best < 0 || cl.makespan() < best) best = cl.makespan();
+        }
+        out.undivided = best;
+    }
+    const bool any_nb = in.has_lo[0] || in.has_hi[0] || !shell_t.empty();
+    CuLine cl(in.ncu);
+    std::vector<BlockDesc> shell_blocks;
+    // 1. x-face slabs of every tile
+    if (in.has_lo[0] && xa > 0) for (auto& tb : all_t) shell_blocks.push_back(desc(tb, 0, xa, BLOCK_SIGNALS, cl.run(xa + o)));
+    if (in.has_hi[0] && xb < nx) for (auto& tb : all_t) shell_blocks.push_back(desc(tb, xb, nx, BLOCK_SIGNALS, cl.run(nx - xb + o)));
+    // 2. y/z shell tiles over the main x range, in chunks that end after ~shell_frac of the launch
+    const double work = (double)all_t.size() * (double)nx;                 // tile-planes
+    const idx_t t_est = (idx_t)(work / (double)in.ncu) + o;
+    if (nmain > 0 && !shell_t.empty()) {
+        idx_t ls = (idx_t)(in.shell_frac * (double)t_est) - o;
+        ls = std::max<idx_t>(std::max<idx_t>(minlen, 24), ls);
+        idx_t ks = std::max<idx_t>(1, (nmain + ls - 1) / ls);
+        // (more shell blocks than CUs would run in rounds and finish no earlier: cap the count at what is resident at a time)
+        while (ks > 1 && (idx_t)shell_t.size() * ks + (idx_t)shell_blocks.size() > in.ncu) ks--;
+        std::vector<BlockDesc> yz;
+        for (idx_t c = 0; c < ks; c++) {
+            const idx_t a = xa + nmain * c / ks, b = xa + nmain * (c + 1) / ks;
+            for (auto& tb : shell_t) yz.push_back(desc(tb, a, b, BLOCK_SIGNALS, 0));
+        }
+        for (auto& d : yz) { d.start = (int)cl.run((d.x1 - d.x0) + o); shell_blocks.push_back(d); }
+    }
+    out.shell_done = any_nb ? cl.makespan() : 0;
+    out.n_signal = (idx_t)shell_blocks.size();
+    // ---- 3. interior tiles over the main range
+    std::vector<BlockDesc> inner_blocks;
+    idx_t inner_makespan = cl.makespan();
+    if (nmain > 0 && !inner_t.empty()) {
+        // (a) greedy budgets: every CU, in the order in which it frees up, takes pieces of the (tile, x) space until time T
+        auto greedy = [&](idx_t T, std::vector<BlockDesc>* emit) -> bool {
+            std::vector<idx_t> av = cl.t;
+            std::vector<size_t> order(av.size());
+            for (size_t i = 0; i < order.size(); i++) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return av[a] < av[b]; });
+            size_t ti = 0;
+            idx_t x = xa;
+            for (size_t oi = 0; oi < order.size() && ti < inner_t.size(); oi++) {
+                idx_t tcu = av[order[oi]];
+                while (ti < inner_t.size()) {
+                    idx_t budget = T - tcu - o;
+                    const idx_t left = xb - x;
+                    if (budget < std::min(minlen, left)) break;
+                    idx_t len = std::min(budget, left);
+                    if (left - len < minlen) len = left;              // no sliver at the end of a tile
+                    if (emit) emit->push_back(desc(inner_t[ti], x, x + len, 0, tcu));
+                    tcu += len + o;
+                    x += len;
+                    if (x >= xb) { ti++; x = xa; }
+                }
+            }
+            return ti >= inner_t.size();
+        };
+        idx_t lo = 1, hi = 4 * (t_est + o) + nmain + cl.makespan();
+        while (lo < hi) { const idx_t mid = (lo + hi) / 2; if (greedy(mid, nullptr)) hi = mid; else lo = mid + 1; }
+        std::vector<BlockDesc> g;
+        greedy(lo, &g);
+        std::stable_sort(g.begin(), g.end(), [](const BlockDesc& a, const BlockDesc& b) { return a.start < b.start; });
+        idx_t g_span = 0;
+        {
+            CuLine c2 = cl;
+            for (auto& d : g) { const idx_t s = c2.run((d.x1 - d.x0) + o); (void)s; }
+            g_span = c2.makespan();
+        }
+        // (b) uniform chunks: every interior tile cut at the same planes (neighbouring tiles march in step and share their
+        // halo lines in L2), chunk count chosen by simulated makespan
+        std::vector<BlockDesc> u;
+        idx_t u_span = -1;
+        for (idx_t k = 1; k <= 64; k++) {
+            if (k > 1 && nmain / k < minlen) break;
+            CuLine c2 = cl;
+            std::vector<BlockDesc> cand;
+            for (idx_t c = 0; c < k; c++) {
+                const idx_t a = xa + nmain * c / k, b = xa + nmain * (c + 1) / k;
+                for (auto& tb : inner_t) cand.push_back(desc(tb, a, b, 0, c2.run((b - a) + o)));
+            }
+            if (u_span < 0 || c2.makespan() < u_span) { u_span = c2.makespan(); u.swap(cand); }
+        }
+        const bool use_g = in.mode == 1 || (in.mode != 2 && g_span * 100 < u_span * 97);     // uniform unless greedy is clearly shorter
+        out.mode_used = use_g ? 1 : 2;
+        inner_blocks = use_g ? g : u;
+        inner_makespan = use_g ? g_span : u_span;
+    }
+    out.makespan = std::max(inner_makespan, cl.makespan());
+    // dispatch order: shell first (dealt over the XCD strips), then the interior in planned start order
+    shell_blocks = deal_over_xcds(shell_blocks);
+    out.blocks = shell_blocks;
+    out.blocks.insert(out.blocks.end(), inner_blocks.begin(), inner_blocks.end());
+    return out;
+}
+
 }  // namespace ykh

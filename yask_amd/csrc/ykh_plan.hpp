@@ -43,4 +43,26 @@ bool plan_halo_slab(int ndd, const idx_t* num_ranks, const idx_t* rank_index, co
 struct WavefrontLaunch { idx_t phase, lo, hi; };
 std::vector<WavefrontLaunch> plan_wavefront(idx_t lo, idx_t hi, idx_t width, idx_t angle, idx_t nphases);
 
+// ---- planned launches of a decomposed rank (ykh_plan.cpp)
+struct BlockPlanIn {
+    idx_t n[MAX_DOMAIN_DIMS] = {1, 1, 1};                 // rank box [0, n)
+    bool has_lo[MAX_DOMAIN_DIMS] = {false, false, false}; // a neighbour rank on the low / high side of dim d
+    bool has_hi[MAX_DOMAIN_DIMS] = {false, false, false};
+    idx_t width[MAX_DOMAIN_DIMS] = {0, 0, 0};             // what a neighbour needs of my boundary in dim d (halo width or -min_exterior)
+    idx_t ty = 1, tz = 1;                                 // tile of the marching kernel (y rows, z elements)
+    idx_t overhead = 8;                                   // plane-iterations a block spends before its first output plane
+    idx_t ncu = 256;                                      // workgroups resident at a time (one per CU)
+    double shell_frac = 0.45;                             // aim: the shell is done after this fraction of the launch
+    int mode = 0;                                         // 0: best of 1 and 2 by simulated makespan; 1: greedy budgets; 2: uniform chunks
+    idx_t min_len = 16;                                   // no block shorter than this (unless its whole range is)
+};
+struct BlockPlan {
+    std::vector<BlockDesc> blocks;       // in dispatch order: signalling (shell) blocks first
+    idx_t n_signal = 0;
+    idx_t makespan = 0, shell_done = 0;  // simulated, in plane-iterations
+    idx_t undivided = 0;                 // the same box as ONE regular launch (tiles x best uniform chunks), simulated the same way
+    int mode_used = 0;
+};
+BlockPlan plan_blocks(const BlockPlanIn& in);
+
 }  // namespace ykh

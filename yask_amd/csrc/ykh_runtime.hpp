@@ -50,6 +50,8 @@ struct KernelVariant {
     int vz = 0;            // elements per thread along z (0: one 16-byte vector)
     int rx = 0;            // >0: not a marching kernel; a block handles rx consecutive x planes (vecpt)
     const void* func = nullptr;   // the __global__ symbol (for hipFuncGetAttributes: scratch use = register spills)
+    bool desc = false;            // marching kernel that reads per-workgroup BlockDescs (PartArgs::blk): planned launches
+    int xover = 0;                // plane-iterations of overhead per block of such a kernel (prologue; the planner's cost model)
 };
 // bytes of scratch (private segment) per thread of a variant's kernel; > 0 means hipcc spilled registers
 size_t variant_scratch_bytes(const KernelVariant& kv);
@@ -121,6 +123,8 @@ public:
     ykh_exchange_fn exch_start = nullptr;   // begin moving all msgs (async on `stream`)
     ykh_exchange_fn exch_wait = nullptr;    // make `stream` wait until they have landed
     ykh_allreduce_fn allreduce = nullptr;
+    void (*exch_reset)(void* user) = nullptr;   // optional: buffers a transport may have cached addresses of are being freed / re-allocated
+    int (*exch_check)(void* user) = nullptr;    // optional: non-zero if an exchange failed asynchronously (called when the streams have drained)
     void* user = nullptr;
     void (*user_free)(void*) = nullptr;     // releases `user` (built-in transports own their state; host callbacks do not)
     bool trace = false;
@@ -425,6 +429,24 @@ public:
     std::vector<hipEvent_t> ext_events;
     hipEvent_t ev_stage = nullptr;
     void launch_interior(const StageMeta& sm, idx_t t, const Box& ib);
+    // ---- planned launches of a decomposed rank: the whole rank box as ONE launch of the marching kernel, shell blocks first,
+    // the halo exchange released from the device when the shell is done (ykh_plan.cpp plan_blocks; replaces exterior slabs +
+    // interior pieces wherever the stage's kernel takes block descriptors)
+    bool planned_launch = true;        // -[no-]hip_planned_launch
+    idx_t shell_pct = 45;              // -hip_shell_pct <n>: the shell should be done after n % of the launch (fewer, longer shell
+                                       // blocks = less prologue overhead but a later start of the exchange)
+    idx_t plan_mode = 0;               // -hip_plan_mode <0|1|2>: interior pieces by simulated makespan / greedy budgets / uniform chunks
+    struct LaunchPlan { std::string key; BlockPlan plan; BlockDesc* dev = nullptr; };
+    std::vector<std::unique_ptr<LaunchPlan>> launch_plans;
+    unsigned* sig_dev = nullptr;       // [0] finished signalling blocks, [1] published epoch, [2] a waiter gave up (error), [3] unused
+    unsigned sig_count = 0, sig_epoch = 0;
+    bool sig_pending = false;          // the launch just issued publishes sig_epoch: exchange_halos() waits for it on the comm stream
+    bool sig_used = false;             // some launch of this run() signalled: run() checks the error word at the end
+    int planned_part(const StageMeta& sm) const;        // the stage's one part if it can run as a planned launch, else -1
+    LaunchPlan* get_launch_plan(int part, const bool* has_lo, const bool* has_hi);
+    void launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hipStream_t s);
+    void drop_launch_plans();
+    void neighbor_sides(bool* has_lo, bool* has_hi) const;
     void time_decomposed_step(const bool* has_lo, const bool* has_hi, int reps, float* ms3);
     // on-chip fusion of two steps per pass (-hip_fuse_steps 2; ykh_starlin2.hpp)
     idx_t fuse_steps = 0;      // -hip_fuse_steps: 2 = on where the solution has such a kernel, 0/1 = off (default: run_solution(a, b) is then
@@ -506,6 +528,11 @@ void launch_copy_pads(const void* src, void* dst, int elem_bytes, const idx_t al
                       hipStream_t s);
 // streaming-bandwidth probe (ykh_util_kernels.hip): kind 0 copy, 1 three reads + one write, 2 read only; GB/s
 double probe_bandwidth(int kind, size_t bytes, int reps);
+
+// stream-ordered waits / stores on words in device memory (ykh_util_kernels.hip): the stream continues when every word i has
+// reached vals[i]; after timeout_s the waiter gives up and raises *err
+void launch_wait_words(int n, const unsigned* const* ptrs, const unsigned* vals, unsigned* err, double timeout_s, hipStream_t s);
+void launch_set_words(int n, unsigned* const* ptrs, const unsigned* vals, hipStream_t s);
 
 // utility kernels (ykh_util_kernels.hip)
 struct BoxCopyArgs {

@@ -122,6 +122,8 @@ Solution::Solution(std::shared_ptr<Env> e, const SolnImpl& im) : env(e), impl(im
 
 Solution::~Solution() {
     drop_step_graphs();
+    drop_launch_plans();
+    if (sig_dev) (void)hipFree(sig_dev);
     free_halo_buffers();
     vars.clear();
     scratch_vars.clear();
@@ -218,8 +220,8 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                                "bind_inner_threads", "bundle_allocs", "init_scratch_vars", "auto_tune",
                                "allow_addl_padding", "round_up_temporal_angles", "print_suffixes", "verbose",
                                "exchange_halos", "auto_tune_each_stage", "trace", "hip_direct_halo", "hip_thin_slab_point_kernel", "hip_round_launches",
-                               "hip_step_timers", "hip_phase_timers", "hip_fast_div"};
-    const char* int_opts[] = {"hip_placement_trials", "hip_var_skew", "hip_step_graphs", "hip_pitch_extra", "hip_ext_streams", "hip_comm_cus", "hip_fuse_steps", "hip_overlap_splits", "min_exterior", "max_threads", "outer_threads", "inner_threads", "numa_pref",
+                               "hip_step_timers", "hip_phase_timers", "hip_fast_div", "hip_planned_launch"};
+    const char* int_opts[] = {"hip_shell_pct", "hip_plan_mode", "hip_placement_trials", "hip_var_skew", "hip_step_graphs", "hip_pitch_extra", "hip_ext_streams", "hip_comm_cus", "hip_fuse_steps", "hip_overlap_splits", "min_exterior", "max_threads", "outer_threads", "inner_threads", "numa_pref",
                               "auto_tune_radius", "thread_divisor", "block_threads", "hip_xchunk", "device_thread_limit"};
     const char* dbl_opts[] = {"auto_tune_trial_secs"};
     const char* str_opts[] = {"auto_tune_targets", "hip_variant"};
@@ -242,6 +244,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                     else if (b == "auto_tune") { auto_tune = val; tune_at_prepare = val; }   // -no-auto_tune: no timing pass at all
                     else if (b == "hip_step_timers") step_timers = val;
                     else if (b == "hip_phase_timers") phase_timers = val;
+                    else if (b == "hip_planned_launch") planned_launch = val;
                     else if (b == "trace") env->trace = val;
                     else if (b == "hip_direct_halo") { direct_halo = val; invalidate(); }
                     else if (b == "hip_thin_slab_point_kernel") thin_slab_point_kernel = val;
@@ -261,7 +264,9 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                 std::string v; idx_t n;
                 if (!next_val(v) || !parse_idx(v, n)) YKH_THROW("option '-" + opt + "' requires an integer value");
                 handled = true;
-                if (opt == "min_exterior") min_exterior = n;
+                if (opt == "min_exterior") { min_exterior = n; drop_launch_plans(); }
+                else if (opt == "hip_shell_pct") { shell_pct = std::min<idx_t>(95, std::max<idx_t>(5, n)); drop_launch_plans(); }
+                else if (opt == "hip_plan_mode") { plan_mode = std::min<idx_t>(2, std::max<idx_t>(0, n)); drop_launch_plans(); }
                 else if (opt == "hip_xchunk") xchunk_override = n;
                 else if (opt == "hip_overlap_splits") overlap_splits = std::max<idx_t>(1, n);
                 else if (opt == "hip_fuse_steps") fuse_steps = n;
@@ -369,6 +374,11 @@ std::string Solution::get_command_line_help() const {
           " -[no-]hip_round_launches          more tiles than CUs: one launch per CU-filling round of tile rows (default on)\n"
           " -[no-]hip_direct_halo             x-face halos of full-dim vars are sent/received in place (default on)\n"
           " -[no-]hip_thin_slab_point_kernel  thin y/z exterior slabs run on the point kernel (default on)\n"
+          " -[no-]hip_planned_launch          decomposed runs: the rank box as ONE launch of the marching kernel, shell blocks first,\n"
+          "                                   the exchange released from the device when they are done (default on; off: exterior\n"
+          "                                   slabs, then the interior in -hip_overlap_splits launches)\n"
+          " -hip_shell_pct <n>                planned launches: the shell is cut so that it is done after n % of the launch (default 45)\n"
+          " -hip_plan_mode <0|1|2>            planned launches: interior pieces 0 = by simulated makespan, 1 = greedy, 2 = uniform chunks\n"
           " -hip_overlap_splits <n>           interior launches per step when halos are overlapped (default 2)\n"
           " -hip_ext_streams <0|1|2>          exterior slabs: 0 one after another (default), 1 side by side on their own streams,\n"
           "                                   2 side by side and beside the interior\n"
@@ -574,6 +584,7 @@ void Solution::prepare() {
     free_halo_buffers();
     alloc_halo_buffers();
     drop_step_graphs();
+    drop_launch_plans();
     // Sub-domain parts: bounding box of the condition inside this rank's domain (the reference's
     // find_bounding_box, src/kernel/lib/setup.cpp:1082-1169); the part is then launched over box ∩ bb only --
     // a free-surface condition `z == last_domain_index(z)` costs one plane instead of a sweep of the grid.
@@ -701,12 +712,14 @@ void Solution::prepare() {
     // kernel 39 Gpoints/s vs 6.5 for the default marching shape; 256^3: star25d 290 vs 209), so time them once.
     // (-no-auto_tune switches this off too: the static defaults are then reproducible run to run)
     else if (tune_at_prepare && (impl.select_by_timing || small_grid) && variant_override.empty() && !force_scalar) tune_variants(true);
+    if (env->exch_reset && env->nranks > 1) env->exch_reset(env->user);      // (var storage may have moved: tune_placement())
     for (auto& h : after_prepare) h(*this);
 }
 
 void Solution::end() {
     synchronize();
     drop_step_graphs();
+    drop_launch_plans();
     free_halo_buffers();
     for (auto& v : vars) v->release();
     for (auto& v : scratch_vars) v->release();
@@ -1002,10 +1015,35 @@ void Solution::time_decomposed_step(const bool* has_lo, const bool* has_hi, int 
     hipEvent_t e[4];
     for (auto& x : e) YKH_HIP(hipEventCreate(&x));
     float acc[3] = {0, 0, 0};
+    bool all_planned = true;
+    for (int st = 0; st < meta->n_stages; st++) all_planned &= planned_part(meta->stages[st]) >= 0;
     for (int r = -1; r < reps; r++) {          // r = -1: warm-up
         // (stage by stage as run() issues them; ms[0] = the exterior of the LAST stage, ms[0] + ms[1] = the whole step --
         //  with -hip_ext_streams 2 the slabs run beside the interior and their time is part of ms[1])
         YKH_HIP(hipEventRecord(e[0], compute_stream));
+        if (all_planned) {
+            // planned launches: ms[0] = from the start of the last stage's launch until its shell blocks have published their
+            // epoch (a waiter on the comm stream, as in run()), ms[1] = from there to the end of the launch
+            for (int st = 0; st < meta->n_stages; st++) {
+                const StageMeta& sm = meta->stages[st];
+                LaunchPlan* lp = get_launch_plan(planned_part(sm), has_lo, has_hi);
+                launch_planned(planned_part(sm), r + 1, *lp, true, compute_stream);
+                sig_pending = false;
+                const unsigned* wp = sig_dev + 1;
+                const unsigned wv = sig_epoch;
+                launch_wait_words(1, &wp, &wv, sig_dev + 2, 20.0, comm_stream);
+                if (st == meta->n_stages - 1) YKH_HIP(hipEventRecord(e[1], comm_stream));
+            }
+            YKH_HIP(hipEventRecord(e[2], compute_stream));
+            for (int st = 0; st < meta->n_stages; st++)
+                for (int k = 0; k < meta->stages[st].n_parts; k++) launch_part(meta->stages[st].parts[k], r + 1, rb, compute_stream);
+            YKH_HIP(hipEventRecord(e[3], compute_stream));
+            YKH_HIP(hipEventSynchronize(e[3]));
+            YKH_HIP(hipStreamSynchronize(comm_stream));
+            if (r < 0) continue;
+            for (int i = 0; i < 3; i++) { float m = 0; YKH_HIP(hipEventElapsedTime(&m, e[i], e[i + 1])); acc[i] += m; }
+            continue;
+        }
         for (int st = 0; st < meta->n_stages; st++) {
             const StageMeta& sm = meta->stages[st];
             const int mode = exterior_mode(sm);
@@ -1029,6 +1067,86 @@ void Solution::time_decomposed_step(const bool* has_lo, const bool* has_hi, int 
     }
     for (int i = 0; i < 3; i++) ms[i] = acc[i] / (reps > 0 ? reps : 1);
     for (auto& x : e) (void)hipEventDestroy(x);
+}
+
+// ------------------------------------------------------------------ planned launches (ykh_plan.cpp plan_blocks)
+void Solution::neighbor_sides(bool* has_lo, bool* has_hi) const {
+    for (int d = 0; d < MAX_DOMAIN_DIMS; d++) {
+        has_lo[d] = d < ndd && env->nranks > 1 && rank_index[d] > 0;
+        has_hi[d] = d < ndd && env->nranks > 1 && rank_index[d] < num_ranks[d] - 1;
+    }
+}
+void Solution::drop_launch_plans() {
+    for (auto& lp : launch_plans) if (lp && lp->dev) (void)hipFree(lp->dev);
+    launch_plans.clear();
+}
+// A stage runs as a planned launch when it is ONE part on a marching kernel that reads block descriptors, over a plain
+// 3-D box: no scratch children (they would have to be evaluated per block), no sub-domain box, no per-point predicate.
+int Solution::planned_part(const StageMeta& sm) const {
+    if (!planned_launch || ndd != 3 || has_outer || force_scalar || sm.n_parts != 1) return -1;
+    const int part = sm.parts[0];
+    const PartMeta& pm = *impl.parts[part].meta;
+    if (pm.is_scratch || pm.has_step_cond || pm.has_step_cond_dev || part_needs_predicate(part)) return -1;
+    if ((size_t)part < part_has_bb.size() && part_has_bb[part]) return -1;
+    if (part_variant[part] < 0) return -1;
+    const KernelVariant& kv = impl.parts[part].variants[part_variant[part]];
+    if (!kv.desc || !kv.star || kv.rx != 0) return -1;
+    return part;
+}
+Solution::LaunchPlan* Solution::get_launch_plan(int part, const bool* has_lo, const bool* has_hi) {
+    const KernelVariant& kv = impl.parts[part].variants[part_variant[part]];
+    std::ostringstream ks;
+    ks << part << ':' << part_variant[part] << '/' << local_size[0] << 'x' << local_size[1] << 'x' << local_size[2] << '/';
+    for (int d = 0; d < 3; d++) ks << (has_lo[d] ? 'l' : '-') << (has_hi[d] ? 'h' : '-');
+    ks << '/' << shell_pct << '/' << plan_mode << '/' << min_exterior << '/' << env->num_cus;
+    const std::string key = ks.str();
+    for (auto& lp : launch_plans) if (lp->key == key) return lp.get();
+    BlockPlanIn in;
+    for (int d = 0; d < 3; d++) {
+        in.n[d] = local_size[d]; in.has_lo[d] = has_lo[d]; in.has_hi[d] = has_hi[d];
+        in.width[d] = std::max<idx_t>(std::max(shared_pad_l_[d], shared_pad_r_[d]), min_exterior);
+    }
+    in.ty = kv.ty; in.tz = kv.tz;
+    in.overhead = kv.xover > 0 ? kv.xover : std::max<idx_t>(1, shared_pad_r_[0] + 1);
+    in.ncu = std::max(1, env->num_cus);
+    in.shell_frac = (double)shell_pct / 100.0;
+    in.mode = (int)plan_mode;
+    auto lp = std::make_unique<LaunchPlan>();
+    lp->key = key;
+    try { lp->plan = plan_blocks(in); } catch (const PlanError& e) { YKH_THROW(e.what()); }
+    if (lp->plan.blocks.empty()) YKH_THROW("planned launch: empty plan");
+    YKH_HIP(hipMalloc(&lp->dev, lp->plan.blocks.size() * sizeof(BlockDesc)));
+    YKH_HIP(hipMemcpyAsync(lp->dev, lp->plan.blocks.data(), lp->plan.blocks.size() * sizeof(BlockDesc), hipMemcpyHostToDevice, compute_stream));
+    YKH_HIP(hipStreamSynchronize(compute_stream));
+    if (env->trace)
+        fprintf(stderr, "planned launch %s: %zu blocks (%lld signalling), simulated shell done at %lld, end at %lld, undivided %lld plane-iterations\n",
+                key.c_str(), lp->plan.blocks.size(), (long long)lp->plan.n_signal, (long long)lp->plan.shell_done,
+                (long long)lp->plan.makespan, (long long)lp->plan.undivided);
+    launch_plans.push_back(std::move(lp));
+    return launch_plans.back().get();
+}
+void Solution::launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hipStream_t s) {
+    const KernelVariant& kv = impl.parts[part].variants[part_variant[part]];
+    PartArgs a;
+    fill_part_args(part, t, rank_box(), a);
+    a.blk = lp.dev;
+    if (signal && lp.plan.n_signal > 0) {
+        if (!sig_dev) {
+            // (zeroed before anything can poll it: a waiter on the comm stream must not read what hipMalloc left there)
+            YKH_HIP(hipMalloc(&sig_dev, 4 * sizeof(unsigned)));
+            YKH_HIP(hipMemsetAsync(sig_dev, 0, 4 * sizeof(unsigned), s));
+            YKH_HIP(hipStreamSynchronize(s));
+            sig_count = sig_epoch = 0;
+        }
+        sig_count += (unsigned)lp.plan.n_signal;
+        a.sig = sig_dev;
+        a.sig_goal = sig_count;
+        a.sig_epoch = ++sig_epoch;
+        sig_pending = true;
+        sig_used = true;
+    }
+    kv.launch(a, dim3((unsigned)lp.plan.blocks.size(), 1, 1), s);
+    YKH_HIP(hipGetLastError());
 }
 
 // ------------------------------------------------------------------ phase timers
@@ -1371,6 +1489,9 @@ void Solution::run(idx_t first_step, idx_t last_step) {
         YKH_HIP(hipEventRecord(step_events[0], compute_stream));
     }
     phase_used = 0;
+    cur_phase = nullptr;
+    sig_pending = false;
+    sig_used = false;
     // Wave-front temporal tiling (-Mbt / -bt > 1): groups of steps go slab by slab (run_wavefront below).  Single rank only:
     // with neighbours the halos would have to be wf_steps x wider (the reference extends them, setup.cpp:863-1020).
     const idx_t wf_steps = std::max<idx_t>(mega_block_size[0], block_size[0]);
@@ -1426,6 +1547,23 @@ void Solution::run(idx_t first_step, idx_t last_step) {
             const StageMeta& sm = meta->stages[st];
             const bool overlap = multi && overlap_comms && have_interior;
             cur_phase = multi ? phase_next() : nullptr;
+            const int pl_part = overlap ? planned_part(sm) : -1;
+            if (pl_part >= 0) {
+                // ONE launch over the rank box: shell blocks first, the exchange released from the device when they are done
+                // (the reference's exterior-first order, context.cpp:377-478, without separate launches)
+                bool lo[MAX_DOMAIN_DIMS], hi[MAX_DOMAIN_DIMS];
+                neighbor_sides(lo, hi);
+                LaunchPlan* lp = get_launch_plan(pl_part, lo, hi);
+                phase_mark(PH_EXT0, compute_stream);
+                launch_planned(pl_part, t, *lp, /*signal=*/true, compute_stream);
+                note_stage_written(sm, t);
+                exchange_halos(t, st, /*start_only=*/true, false);       // (marks PH_EXT1 on the comm stream, after its wait)
+                phase_mark(PH_INT1, compute_stream);
+                exchange_halos(t, st, false, /*finish_only=*/true);
+                phase_mark(PH_WAIT1, compute_stream);
+                cur_phase = nullptr;
+                continue;
+            }
             int n_ext = 0;
             const int ext_mode = overlap ? exterior_mode(sm) : 0;
             if (overlap) {
@@ -1461,6 +1599,16 @@ void Solution::run(idx_t first_step, idx_t last_step) {
     }
     YKH_HIP(hipStreamSynchronize(compute_stream));
     if (multi) YKH_HIP(hipStreamSynchronize(comm_stream));
+    if (sig_used && sig_dev) {
+        unsigned err = 0;
+        YKH_HIP(hipMemcpy(&err, sig_dev + 2, sizeof(err), hipMemcpyDeviceToHost));
+        if (err) {
+            (void)hipMemset(sig_dev + 2, 0, sizeof(unsigned));
+            YKH_THROW("run_solution(): a halo exchange waited in vain for the shell blocks of a planned launch (device-side signal timed out)");
+        }
+    }
+    if (multi && env->exch_check && env->exch_check(env->user) != 0)
+        YKH_THROW("run_solution(): the halo transport reports a failed exchange");
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stats.elapsed_secs += secs;
     stats.halo_secs += halo_secs;

@@ -106,6 +106,8 @@ KernelVariant march_variant() {
     KernelVariant kv{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_march<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT>};
     kv.vz = VZ;
     kv.func = reinterpret_cast<const void*>(&march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT>);
+    kv.desc = true;                       // takes planned launches (block descriptors, completion signal)
+    kv.xover = C::XOVER;                  // a block's prologue: the deepest x queue it fills before its first plane
     return kv;
 }
 
@@ -122,6 +124,8 @@ KernelVariant starlin_variant() {
     KernelVariant kv{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_starlin<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL>};
     kv.vz = VZ;
     kv.func = reinterpret_cast<const void*>(&starlin_kernel<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL>);
+    kv.desc = true;                       // takes planned launches (block descriptors, completion signal)
+    kv.xover = C::XH + 1;                 // a block runs XH plane-iterations before its first output plane (+ the queue loads)
     return kv;
 }
 

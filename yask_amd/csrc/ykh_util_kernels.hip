@@ -229,6 +229,56 @@ __global__ void __launch_bounds__(256) bw_probe_k(const f4* __restrict__ a, cons
     }
     if constexpr (KIND == 2) if (acc.x == 123.456f) d[0] = acc;
 }
+// ------------------------------------------------------------------ stream-ordered waits on words in device memory
+// wait_words_kernel: ONE wave; lane i polls word i until it has reached its value (wrap-safe `>=`), then the kernel ends and the
+// stream goes on.  Used (a) by the comm stream to wait for the shell blocks of a planned launch that is still running on the
+// compute stream (Solution::launch_planned: block_done() publishes the epoch), and (b) by the IPC transport for the flags its
+// peers write into this rank's mailbox (ykh_ipc.cpp).  It occupies one wave slot and issues one 4-byte system-scope load per
+// lane and microsecond: nothing a marching kernel notices.  A waiter that is never released would hang the stream (and, with
+// it, the box): after `spins` polls (~1 us each) it gives up, raises *err and lets the stream continue -- the host reports
+// the error at its next synchronisation point.
+struct WaitWords { const unsigned* p[32]; unsigned v[32]; int n; };
+__global__ void __launch_bounds__(64) wait_words_kernel(WaitWords w, unsigned* err, unsigned spins) {
+    const int i = threadIdx.x;
+    bool ok = i >= w.n;
+    for (unsigned k = 0; k < spins; k++) {
+        if (!ok) ok = (int)(__hip_atomic_load(w.p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - w.v[i]) >= 0;
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (!ok && err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // what was released before the words were raised is visible to what follows
+}
+void launch_wait_words(int n, const unsigned* const* ptrs, const unsigned* vals, unsigned* err, double timeout_s, hipStream_t s) {
+    if (n <= 0) return;
+    for (int base = 0; base < n; base += 32) {
+        WaitWords w;
+        w.n = std::min(32, n - base);
+        for (int i = 0; i < 32; i++) { w.p[i] = ptrs[base + std::min(i, w.n - 1)]; w.v[i] = vals[base + std::min(i, w.n - 1)]; }
+        const unsigned spins = (unsigned)std::min(4.0e9, std::max(1.0e3, timeout_s * 1.0e6));
+        hipLaunchKernelGGL(wait_words_kernel, dim3(1), dim3(64), 0, s, w, err, spins);
+    }
+    YKH_HIP(hipGetLastError());
+}
+// set_words_kernel: lane i stores value i to word i with system scope, after a system-scope release (what this stream did before
+// -- a copy into a peer's buffer -- is visible to whoever sees the word).
+struct SetWords { unsigned* p[32]; unsigned v[32]; int n; };
+__global__ void __launch_bounds__(64) set_words_kernel(SetWords w) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int i = threadIdx.x;
+    if (i < w.n) __hip_atomic_store(w.p[i], w.v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_set_words(int n, unsigned* const* ptrs, const unsigned* vals, hipStream_t s) {
+    for (int base = 0; base < n; base += 32) {
+        SetWords w;
+        w.n = std::min(32, n - base);
+        for (int i = 0; i < 32; i++) { w.p[i] = ptrs[base + std::min(i, w.n - 1)]; w.v[i] = vals[base + std::min(i, w.n - 1)]; }
+        hipLaunchKernelGGL(set_words_kernel, dim3(1), dim3(64), 0, s, w);
+    }
+    YKH_HIP(hipGetLastError());
+}
+
 double probe_bandwidth(int kind, size_t bytes, int reps) {
     if (kind < 0 || kind > 2) YKH_THROW("probe_bandwidth: kind must be 0 (copy), 1 (3 reads + 1 write) or 2 (read)");
     if (bytes < (1u << 20)) bytes = (size_t)1 << 30;

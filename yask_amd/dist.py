@@ -7,6 +7,9 @@ process to its GPU, tells the env its rank, and installs a halo transport:
 
   "rccl"  (default on GPUs): the library's built-in RCCL send/recv (yask_amd/csrc/ykh_rccl.cpp); the
            128-byte ncclUniqueId is created on rank 0 and broadcast through torch.distributed.
+  "ipc":   the library's device-to-device transport between the GPUs of one host: copies straight into the neighbour's
+           buffers (HIP IPC memory handles; SDMA over xGMI, no compute units), ordered by flag words in device memory
+           (yask_amd/csrc/ykh_ipc.cpp).  Ranks may share a device (one-GPU tests).
   "torch": Python callbacks that move the packed halo buffers with torch.distributed P2P ops
            (batch_isend_irecv on zero-copy views of the library's device buffers when the backend is
            nccl; staged through host memory for gloo, which is how the N>1 path is tested on one GPU
@@ -162,6 +165,23 @@ def new_env(factory, transport="rccl", strict=False):
                 raise RuntimeError("YASK error: the native RCCL halo transport could not be initialised on every rank "
                                    "(see the messages above); refusing to fall back to the torch transport")
             print(f"yask_amd.dist[{rank}]: falling back to the torch.distributed halo transport", flush=True)
+            used = "torch"
+    if transport == "ipc":
+        # device-to-device copies into the neighbour's buffers (HIP IPC handles) + stream-ordered flag words (csrc/ykh_ipc.cpp);
+        # its control mesh listens next to the launcher's port
+        port = int(os.environ.get("MASTER_PORT", "29533")) + 48 + int(os.environ.get("YASK_IPC_PORT_OFFSET", "0"))
+        ok = 1
+        try:
+            env.init_ipc(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port)
+        except Exception as e:
+            print(f"yask_amd.dist[{rank}]: IPC halo transport unavailable ({e!r})", flush=True)
+            ok = 0
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        flag = torch.tensor([ok], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if strict:
+                raise RuntimeError("YASK error: the IPC halo transport could not be initialised on every rank (see the messages above)")
             used = "torch"
     if used == "torch":
         tr = TorchTransport()

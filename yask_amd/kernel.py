@@ -558,6 +558,10 @@ class yk_env:
     def init_tcp(self, rank, num_ranks, addr="127.0.0.1", base_port=29600):
         self._lib.call_rc("yk_env_init_tcp", self._h, int(rank), int(num_ranks), _b(addr), int(base_port))
 
+    def init_ipc(self, rank, num_ranks, addr="127.0.0.1", base_port=29600):
+        """Device-to-device transport between the ranks of one host (HIP IPC handles + stream-ordered flags, ykh_ipc.cpp)."""
+        self._lib.call_rc("yk_env_init_ipc", self._h, int(rank), int(num_ranks), _b(addr), int(base_port))
+
     def transport_loopback(self, nbytes=1 << 22):
         """Run the installed halo transport once with this rank as its own peer and verify the bytes."""
         self._lib.call_rc("yk_env_transport_loopback", self._h, int(nbytes))
