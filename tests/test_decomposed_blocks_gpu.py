@@ -168,7 +168,7 @@ def _check_against_one_rank_and_reference(parts, one, stencil, g, steps, stride,
 @pytest.mark.parametrize("world,nr,transport,opts", [
     (2, (1, 1, 2), "ipc", ""),                                                 # two 1024 x 1024 x 512 blocks (config 4's block), z face
     (8, (2, 2, 2), "ipc", ""),                                                 # eight 512^3 blocks, three faces each, planned launches
-    (8, (2, 2, 2), "tcp", "-no-hip_planned_launch -no-hip_thin_slab_point_kernel"),   # round 2's slabs + split interior at this size
+    (8, (2, 2, 2), "tcp", "-no-hip_planned_launch -no-hip_thin_slab_point_kernel"),   # round 2's slabs + interior at this size
 ])
 def test_iso3dfd_1024_cut_over_ranks_equals_one_rank_and_the_reference(gpu, world, nr, transport, opts):
     meta = INDEX["c2_iso3dfd_1024_s2_lattice"]

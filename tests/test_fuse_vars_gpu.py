@@ -49,11 +49,10 @@ def test_two_solutions_share_one_wavefield(gpu):
     a.run_solution(0, 1)
     assert pb.get_first_valid_step_index() == pa.get_first_valid_step_index() == 1
     assert np.array_equal(whole(b, "p", 2), whole(a, "p", 2))
-    ref = O.run_iso3dfd(SIZE, 4)
-    assert O.rel_linf(whole(b, "p", 2), ref[("p", 2)]) <= 2e-5
+    assert O.rel_linf(whole(b, "p", 2), O.run_iso3dfd(SIZE, 2)[("p", 2)]) <= 2e-5
     # ... and B continues from there on the same data: steps 2, 3 through B == four steps of one solution
     b.run_solution(2, 3)
-    assert O.rel_linf(whole(a, "p", 4), ref[("p", 4)]) <= 2e-5
+    assert O.rel_linf(whole(a, "p", 4), O.run_iso3dfd(SIZE, 4)[("p", 4)]) <= 2e-5
     assert np.array_equal(whole(a, "p", 4), whole(b, "p", 4))
 
 

@@ -358,7 +358,7 @@ def test_wavefront_plan_reproduces_plain_sweeps_in_place(nx, width, radius, nste
 
 
 # ------------------------------------------------------------------ (f) planned launch of a decomposed rank: the block list
-def _plan(n, lo, hi, width=(8, 8, 8), ty=32, tz=128, overhead=9, ncu=256, shell_pct=45, mode=0):
+def _plan(n, lo, hi, width=(8, 8, 8), ty=32, tz=128, overhead=9, ncu=256, shell_pct=55, mode=0):
     A3, I3 = _capi.idx_t * 3, C.c_int * 3
     info = (_capi.idx_t * 5)()
     args = (A3(*n), I3(*lo), I3(*hi), A3(*width), ty, tz, overhead, ncu, shell_pct, mode)
@@ -412,7 +412,7 @@ def test_block_plans_of_the_baseline_blocks_stay_close_to_the_undivided_sweep():
     """The cost model's verdict for the blocks BASELINE configs 2 / 4 give a GPU of the 2x2x2 grid (iso3dfd: tile 128 x 32,
     9 plane-iterations of prologue per block, 256 CUs): simulated makespan of the planned launch vs the same box as one regular
     launch.  Round 2's separate launches measured 1.22-1.51x (512^3) and 1.18-1.29x (1024 x 1024 x 512) on the GPU."""
-    for n, bound in (((512, 512, 512), 1.10), ((1024, 1024, 512), 1.07), ((512, 1024, 1024), 1.03)):
+    for n, bound in (((512, 512, 512), 1.08), ((1024, 1024, 512), 1.03), ((512, 1024, 1024), 1.03)):
         hi = (1, 1, 1) if n[1] == n[0] or n[2] == 512 else (1, 0, 0)
         blocks, info = _plan(n, (0, 0, 0), hi)
         n_sig, shell_done, makespan, undivided, mode = info

@@ -98,11 +98,11 @@ def test_two_stage_in_place_solution(gpu):
 
 
 def test_fused_passes_come_first_graphs_take_nothing_from_them(gpu):
-    """3axis r=1 runs two steps per pass by default; the replay only ever covers the plain loop behind it."""
+    """3axis r=1 with -hip_fuse_steps 2 runs two steps per pass; the replay only ever covers the plain loop behind it."""
     size = (40, 61, 130)
     init = {"A": (0.0, 1.0, 0)}
-    g = make("3axis_r1", size, "-hip_step_graphs 1", init)
-    p = make("3axis_r1", size, "-hip_step_graphs 0", init)
+    g = make("3axis_r1", size, "-hip_step_graphs 1 -hip_fuse_steps 2", init)
+    p = make("3axis_r1", size, "-hip_step_graphs 0 -hip_fuse_steps 2", init)
     g.run_solution(0, 8)
     p.run_solution(0, 8)
     assert g.get_stats().get_num_fused_passes() == 4

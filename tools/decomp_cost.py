@@ -27,7 +27,8 @@ SSG_CASES = [
     ("ssg 1024^3 global / 8 GPUs, 2x2x2, local 512^3", (512, 512, 512), (0, 0, 0), (1, 1, 1)),
 ]
 CONFIGS = [  # label, options
-    ("planned pct45 auto", "-hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 0"),
+    ("planned rounds pct55 (default)", "-hip_planned_launch -hip_shell_pct 55 -hip_plan_mode 0"),
+    ("planned rounds pct35", "-hip_planned_launch -hip_shell_pct 35 -hip_plan_mode 0"),
     ("planned pct45 greedy", "-hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 1"),
     ("planned pct45 uniform", "-hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 2"),
     ("planned pct30 greedy", "-hip_planned_launch -hip_shell_pct 30 -hip_plan_mode 1"),

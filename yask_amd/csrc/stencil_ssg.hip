@@ -52,6 +52,9 @@ const SolnImpl& ykh_solution_impl() {
             //  alone already moves 6.27 TB/s; the exact shape gains 1.9 %: 1.674 -> 1.643 ms, gpurun_out/r03m)
             p.set_default("march_v4_z128_y16_nt_hr_fd_w2");
             p.set_exact_div("march_v4_z128_y16_nt_hr_ps_t2_lo_w2");
+            // planned launches of a decomposed rank (descriptor-reading twins, ~5 more SGPRs): the default's twin spills (it sits at
+            // 256 VGPRs); the late-refill form of the same arithmetic has room (232 VGPRs)
+            p.set_planned("march_v4_z128_y16_nt_hr_fd_lo_w2");
             s.parts.push_back(p);
         }
         return s;

@@ -5,7 +5,7 @@ namespace ykh {
 using namespace ykh_gen_ssg;
 void ssg_variants_k1(PartImpl& p) {
     p.variants.push_back(march_variant<part_1, 4, 32, 8, 2>());
-    p.variants.push_back(march_variant<part_1, 2, 64, 8, 2>());
+    p.variants.push_back(march_variant_planned<part_1, 2, 64, 8, 2>());      // (+ twin for planned launches: the multi-rank tests' shape)
     p.variants.push_back(march_variant<part_1, 2, 32, 16, 2>());
     p.variants.push_back(march_variant<part_1, 2, 64, 4, 2>());
     p.variants.push_back(march_variant<part_1, 2, 64, 8, 2, 1, true>());   // strict program order (pin() after every temporary)

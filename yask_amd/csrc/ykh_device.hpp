@@ -82,21 +82,25 @@ struct PartArgs {
     unsigned sig_epoch;           // ... this epoch in sig[1]: the comm stream's wait_epoch_kernel then lets the halo exchange start
 };
 
-// The (y, z) tile and x range of the calling workgroup of a marching kernel, and the box its stores are clipped to.
-struct BlockBox { int xs, xe, yt0, y1, zt0, z0, z1, flags; };
-template <int VZ, int TZ, int TY>
+// The (y, z) tile and x range of the calling workgroup of a marching kernel.  Stores are clipped to the launch's box x0..z1
+// either way (a planned launch covers the rank box; each of its blocks is one whole tile of the regular tiling, so a thread
+// can only reach points of its own tile) -- the descriptor's y1 / z1 are for the host-side checks.
+struct BlockBox { int xs, xe, yt0, zt0, flags; };
+template <int VZ, int TZ, int TY, bool DESC>
 __device__ __forceinline__ BlockBox block_box(const PartArgs& a) {
     BlockBox b;
-    if (a.blk) {
+    // (DESC is a compile-time flag: the descriptor-reading twin of a kernel shape is a separate instantiation, so that the
+    //  regular kernel keeps its register allocation -- the twin needs ~5 more SGPRs, which tips shapes at the 256-VGPR limit
+    //  into scratch)
+    if constexpr (DESC) {
         // planned launch: everything comes from the descriptor (uniform: kept in SGPRs)
         const BlockDesc* d = a.blk + blockIdx.x;
         b.xs = __builtin_amdgcn_readfirstlane(d->x0); b.xe = __builtin_amdgcn_readfirstlane(d->x1);
-        b.yt0 = __builtin_amdgcn_readfirstlane(d->y0); b.y1 = __builtin_amdgcn_readfirstlane(d->y1);
-        b.z0 = __builtin_amdgcn_readfirstlane(d->z0); b.z1 = __builtin_amdgcn_readfirstlane(d->z1);
+        b.yt0 = __builtin_amdgcn_readfirstlane(d->y0);
+        b.zt0 = __builtin_amdgcn_readfirstlane(d->z0) & ~(VZ - 1);
         b.flags = __builtin_amdgcn_readfirstlane(d->flags);
-        b.zt0 = b.z0 & ~(VZ - 1);
         return b;
-    }
+    } else {
     // XCD-aware tile assignment: block i runs on XCD i % 8; each XCD owns a contiguous range of (y,z) tiles, so that
     // neighbouring tiles share one L2
     const int ntiles = a.ntz * a.nty * a.nxc;
@@ -109,8 +113,9 @@ __device__ __forceinline__ BlockBox block_box(const PartArgs& a) {
     b.yt0 = a.y0 + ty_i * TY;
     b.xs = a.x0 + xc_i * a.xchunk;
     b.xe = (b.xs + a.xchunk < a.x1) ? b.xs + a.xchunk : a.x1;
-    b.y1 = a.y1; b.z0 = a.z0; b.z1 = a.z1; b.flags = 0;
+    b.flags = 0;
     return b;
+    }
 }
 // End of a signalling block of a planned launch: its stores are made visible (system scope: the next reader may be a copy
 // engine or a peer), then it counts itself done; the block that completes the count publishes the launch's epoch.

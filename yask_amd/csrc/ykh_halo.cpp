@@ -29,6 +29,12 @@ static bool slab_for(const Solution& s, const Var& v, const Solution::Neighbor& 
         g.halo_l[d] = v.halo_l[d]; g.halo_r[d] = v.halo_r[d];
     }
     g.l1_norm = v.l1_norm;
+    if (s.wf_multi()) {
+        // wave-front tiling across ranks: every var a phase may read on its extended box needs its neighbours' data
+        // wf_ext further out -- vars without a halo included -- and the extended boxes have edges and corners
+        for (int d = 0; d < MAX_DOMAIN_DIMS; d++) g.wext[d] = v.uses_domain[d] ? s.wf_ext(d) : 0;
+        g.l1_norm = MAX_DOMAIN_DIMS;
+    }
     PlanNeighbor pn;
     pn.rank = nb.rank; pn.l1 = nb.l1;
     for (int d = 0; d < MAX_DOMAIN_DIMS; d++) pn.ofs[d] = nb.ofs[d];
@@ -52,7 +58,7 @@ void Solution::alloc_halo_buffers() {
         x->send_cap = sb * elem_bytes();
         x->recv_cap = rb * elem_bytes();
         // in-place transfer? (decided from geometry only, so both ends of a link agree)
-        x->direct = direct_halo && ndd == 3 && nb.ofs[0] != 0 && nb.ofs[1] == 0 && nb.ofs[2] == 0 &&
+        x->direct = direct_halo && !wf_multi() && ndd == 3 && nb.ofs[0] != 0 && nb.ofs[1] == 0 && nb.ofs[2] == 0 &&
                     x->send.size() == x->recv.size() && !x->send.empty();
         for (auto* lst : {&x->send, &x->recv})
             for (const Slab& sl : *lst) {

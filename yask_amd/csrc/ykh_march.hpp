@@ -231,7 +231,8 @@ struct MarchAcc {
 // interior (ssg: 4 planes x ~4.7 MB of plane data per XCD against 4 MiB of L2: the halo lines come over the fabric a second
 // time).  With HR the halo of plane x+xhi is requested together with the interior and parked in an LDS ring of xhi+1
 // planes until the plane becomes the centre; every ring entry is written and read back by the same thread (no barrier).
-template <class P, int VZ, int TZL, int TYL, int MINW, int RY = 1, bool PIN = false, int PD = 1, int FL = 0>
+// DESC: the twin that takes its tile and x range from a block descriptor (planned launches, ykh_plan.cpp) and signals when done.
+template <class P, int VZ, int TZL, int TYL, int MINW, int RY = 1, bool PIN = false, int PD = 1, int FL = 0, bool DESC = false>
 __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a) {
     constexpr int NTS = FL & 1;
     constexpr bool HR = (FL & 2) != 0;
@@ -258,11 +259,10 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
     T* slab = reinterpret_cast<T*>(ykh_smem);
     T* ring = slab + 2 * (C::SLAB_TOT > 0 ? C::SLAB_TOT : 1);
 
-    const BlockBox bb = block_box<VZ, C::TZ, C::TY>(a);      // regular tiling of the box, or a planned launch's descriptor
+    const BlockBox bb = block_box<VZ, C::TZ, C::TY, DESC>(a);      // regular tiling of the box, or a planned launch's descriptor
     const int tid = threadIdx.x;
     const int lz = tid % TZL, ly = tid / TZL;
     const int zt0 = bb.zt0, yt0 = bb.yt0, xs = bb.xs, xe = bb.xe;
-    const int bz0 = bb.z0, bz1 = bb.z1, by1 = bb.y1;           // the box the stores are clipped to
     if (xs >= xe) return;
     const int myz = zt0 + lz * VZ;
     const int myy0 = yt0 + ly * RY;       // first of this thread's RY rows
@@ -464,10 +464,10 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
             V out[MAX_GROUPS];
             MarchAcc<C, P, PIN, OPS, PH, LO> acc{a, q[j], mreg[S][j], nxt[S][j], sb, ly * RY + j, lz, x, myy, myz, out, m1};
             P::eval(acc);
-            if (x < xe && myy < by1 && myz < bz1 && myz + VZ > bz0) {
+            if (x < xe && myy < a.y1 && myz < a.z1 && myz + VZ > a.z0) {
                 // (written groups are vars over all dims; the store predicate implies yc[j] == myy, zc == myz)
                 const idx_t xo = org + (idx_t)x * a.sx;
-                const bool whole = myz >= bz0 && myz + VZ <= bz1;
+                const bool whole = myz >= a.z0 && myz + VZ <= a.z1;
                 static_for<P::n_writes>([&](auto wc) {
                     constexpr int g = P::writes[decltype(wc)::value];
                     auto ob = sbase((T*)a.ptr[g] + xo);
@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
                     else
                         static_for<VZ>([&](auto ec) {
                             constexpr int e = decltype(ec)::value;
-                            if (myz + e >= bz0 && myz + e < bz1) stv_b<T>(ob, ooff[j] + e * (unsigned)sizeof(T), out[g][e]);
+                            if (myz + e >= a.z0 && myz + e < a.z1) stv_b<T>(ob, ooff[j] + e * (unsigned)sizeof(T), out[g][e]);
                         });
                 });
             }
@@ -518,7 +518,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
             });
         }
     }
-    block_done(a, bb.flags);
+    if constexpr (DESC) block_done(a, bb.flags);
 }
 
 }  // namespace ykh

@@ -152,11 +152,11 @@ bool plan_halo_slab(int ndd, const idx_t* num_ranks, const idx_t* rank_index, co
             }
             lo[d] = l; n[d] = h - l;
         } else if (sending) {
-            idx_t w = (o < 0) ? v.halo_r[d] : v.halo_l[d];
+            idx_t w = ((o < 0) ? v.halo_r[d] : v.halo_l[d]) + v.wext[d];
             lo[d] = (o < 0) ? 0 : sz - w;
             n[d] = w;
         } else {
-            idx_t w = (o < 0) ? v.halo_l[d] : v.halo_r[d];
+            idx_t w = ((o < 0) ? v.halo_l[d] : v.halo_r[d]) + v.wext[d];
             lo[d] = (o < 0) ? -w : sz;
             n[d] = w;
         }
@@ -224,10 +224,114 @@ std::vector<T> deal_over_xcds(const std::vector<T>& v) {
 }
 }  // namespace
 
+// Mode 0 ("rounds"), the default.  What the first planner (modes 1 / 2 below) got wrong, measured on the GPU (gpurun_out/r3a):
+// pieces sized per CU start at different times and places, so the ~250 concurrent workgroups of a launch march through ~250
+// different x planes -- and the kernel runs 1.5x slower per plane than in a regular launch, where all tiles of a chunk sweep
+// the same planes at the same time (DRAM pages, TLB reach and the L2 sharing of halo lines all depend on it; round 2 had seen
+// 10 % from mere drift).  So: EVERY tile is cut at the same k planes (the regular launch's own structure, k chosen so that the
+// launch takes at least two rounds of workgroups), all blocks have the same length and therefore start and end together round
+// after round, and only the ORDER is planned: first every block a neighbour needs something of -- all chunks of the y/z shell
+// tiles, and the first / last chunk of every tile where an x neighbour exists (its face planes are complete when the chunk
+// ends) -- then the rest.  No thin slabs, no extra prologues beyond those of the k chunks.
+static BlockPlan plan_rounds(const BlockPlanIn& in) {
+    BlockPlan out;
+    const idx_t nx = in.n[0], ny = in.n[1], nz = in.n[2];
+    const idx_t o = std::max<idx_t>(0, in.overhead), minlen = std::max<idx_t>(1, in.min_len);
+    std::vector<TileBox> tiles;
+    std::vector<char> shell;
+    auto touches = [&](idx_t a, idx_t b, idx_t n, int d) {
+        const idx_t w = std::max<idx_t>(1, in.width[d]);
+        return (in.has_lo[d] && a < w) || (in.has_hi[d] && b > n - w);
+    };
+    for (idx_t y0 = 0; y0 < ny; y0 += in.ty)
+        for (idx_t z0 = 0; z0 < nz; z0 += in.tz) {
+            TileBox tb{y0, std::min(y0 + in.ty, ny), z0, std::min(z0 + in.tz, nz)};
+            tiles.push_back(tb);
+            shell.push_back(touches(tb.y0, tb.y1, ny, 1) || touches(tb.z0, tb.z1, nz, 2));
+        }
+    const idx_t wx = std::max<idx_t>(1, in.width[0]);
+    auto build = [&](idx_t k, std::vector<BlockDesc>* blocks, idx_t* n_sig, idx_t* shell_done, idx_t* makespan) {
+        std::vector<BlockDesc> p1, p2;
+        for (idx_t c = 0; c < k; c++) {
+            const idx_t a = nx * c / k, b = nx * (c + 1) / k;
+            // (an x neighbour needs my first / last wx planes: every chunk that holds some of them)
+            const bool xface = (in.has_lo[0] && a < wx) || (in.has_hi[0] && b > nx - wx);
+            for (size_t i = 0; i < tiles.size(); i++) {
+                BlockDesc d;
+                d.x0 = (int)a; d.x1 = (int)b; d.y0 = (int)tiles[i].y0; d.y1 = (int)tiles[i].y1; d.z0 = (int)tiles[i].z0; d.z1 = (int)tiles[i].z1;
+                d.flags = (shell[i] || xface) ? BLOCK_SIGNALS : 0;
+                d.start = 0;
+                (d.flags ? p1 : p2).push_back(d);
+            }
+        }
+        std::vector<BlockDesc> all = p1;
+        all.insert(all.end(), p2.begin(), p2.end());
+        // simulate the dispatch; within each round of ncu blocks, deal the blocks over the XCD strips
+        CuLine cl(in.ncu);
+        idx_t sd = 0;
+        for (auto& d : all) {
+            d.start = (int)cl.run((d.x1 - d.x0) + o);
+            if (d.flags) sd = std::max<idx_t>(sd, d.start + (d.x1 - d.x0) + o);
+        }
+        if (blocks) {
+            blocks->clear();
+            for (size_t r0 = 0; r0 < all.size(); r0 += (size_t)in.ncu) {
+                std::vector<BlockDesc> seg(all.begin() + r0, all.begin() + std::min(all.size(), r0 + (size_t)in.ncu));
+                // (the shell blocks of a segment stay in front of its other blocks: dealt separately)
+                std::vector<BlockDesc> a1, a2;
+                for (auto& d : seg) (d.flags ? a1 : a2).push_back(d);
+                a1 = deal_over_xcds(a1); a2 = deal_over_xcds(a2);
+                blocks->insert(blocks->end(), a1.begin(), a1.end());
+                blocks->insert(blocks->end(), a2.begin(), a2.end());
+            }
+        }
+        *n_sig = (idx_t)p1.size(); *shell_done = p1.empty() ? 0 : sd; *makespan = cl.makespan();
+    };
+    // candidates: k chunks per tile.  Among those within 20 % of the shortest launch: the shortest whose shell is done by shell_frac
+    // of it; if none is, the one with the earliest shell.
+    struct Cand { idx_t k, span; double frac; };
+    std::vector<Cand> cands;
+    idx_t shortest = -1;
+    for (idx_t k = 1; k <= 64; k++) {
+        if (k > 1 && nx / k < minlen) break;
+        idx_t ns, sd, ms;
+        build(k, nullptr, &ns, &sd, &ms);
+        cands.push_back({k, ms, ms > 0 ? (double)sd / (double)ms : 1.0});
+        if (shortest < 0 || ms < shortest) shortest = ms;
+    }
+    idx_t best_k = 1, best_span = -1;
+    double best_frac = 2.0;
+    bool best_ok = false;
+    for (const Cand& c : cands) {
+        if (c.span * 5 > shortest * 6) continue;
+        const bool ok = c.frac <= in.shell_frac + 1e-9;
+        bool better;
+        if (ok != best_ok) better = ok;
+        else if (ok) better = best_span < 0 || c.span < best_span;
+        else better = c.frac < best_frac - 0.02 || (c.frac < best_frac + 0.02 && (best_span < 0 || c.span < best_span));
+        if (better) { best_k = c.k; best_span = c.span; best_frac = c.frac; best_ok = ok; }
+    }
+    build(best_k, &out.blocks, &out.n_signal, &out.shell_done, &out.makespan);
+    out.mode_used = 3;
+    // the undivided box as one regular launch, for reference
+    idx_t best = -1;
+    for (idx_t k = 1; k <= 64; k++) {
+        const idx_t len = (nx + k - 1) / k;
+        if (k > 1 && len < 32) break;
+        CuLine cl(in.ncu);
+        for (idx_t c = 0; c * len < nx; c++)
+            for (size_t i = 0; i < tiles.size(); i++) cl.run(std::min(len, nx - c * len) + o);
+        if (best < 0 || cl.makespan() < best) best = cl.makespan();
+    }
+    out.undivided = best;
+    return out;
+}
+
 BlockPlan plan_blocks(const BlockPlanIn& in) {
     BlockPlan out;
     const idx_t nx = in.n[0], ny = in.n[1], nz = in.n[2];
     if (nx < 1 || ny < 1 || nz < 1 || in.ty < 1 || in.tz < 1 || in.ncu < 1) throw PlanError("plan_blocks: bad box or tile");
+    if (in.mode == 0) return plan_rounds(in);
     const idx_t o = std::max<idx_t>(0, in.overhead), minlen = std::max<idx_t>(1, in.min_len);
     auto desc = [](const TileBox& tb, idx_t x0, idx_t x1, int flags, idx_t start) {
         BlockDesc d;
@@ -343,7 +447,7 @@ BlockPlan plan_blocks(const BlockPlanIn& in) {
             }
             if (u_span < 0 || c2.makespan() < u_span) { u_span = c2.makespan(); u.swap(cand); }
         }
-        const bool use_g = in.mode == 1 || (in.mode != 2 && g_span * 100 < u_span * 97);     // uniform unless greedy is clearly shorter
+        const bool use_g = in.mode == 1;
         out.mode_used = use_g ? 1 : 2;
         inner_blocks = use_g ? g : u;
         inner_makespan = use_g ? g_span : u_span;

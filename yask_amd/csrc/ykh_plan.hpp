@@ -31,6 +31,7 @@ struct VarGeom {
     idx_t dom_size[MAX_DOMAIN_DIMS];
     idx_t halo_l[MAX_DOMAIN_DIMS], halo_r[MAX_DOMAIN_DIMS];
     int l1_norm;
+    idx_t wext[MAX_DOMAIN_DIMS] = {0, 0, 0};     // wave-front extension: what travels to a neighbour is this much wider (Solution::wf_ext_)
 };
 
 void compact_factors(idx_t N, int nd, idx_t* f);
@@ -53,7 +54,9 @@ struct BlockPlanIn {
     idx_t overhead = 8;                                   // plane-iterations a block spends before its first output plane
     idx_t ncu = 256;                                      // workgroups resident at a time (one per CU)
     double shell_frac = 0.45;                             // aim: the shell is done after this fraction of the launch
-    int mode = 0;                                         // 0: best of 1 and 2 by simulated makespan; 1: greedy budgets; 2: uniform chunks
+    int mode = 0;                                         // 0: rounds -- every tile cut at the same planes, equal blocks, shell blocks first
+                                                          // (default); 1: thin x slabs + shell chunks + greedy per-CU budgets; 2: the same
+                                                          // with uniform interior chunks (the first planner: measured 1.3-1.6x, kept for A/B)
     idx_t min_len = 16;                                   // no block shorter than this (unless its whole range is)
 };
 struct BlockPlan {
@@ -61,7 +64,7 @@ struct BlockPlan {
     idx_t n_signal = 0;
     idx_t makespan = 0, shell_done = 0;  // simulated, in plane-iterations
     idx_t undivided = 0;                 // the same box as ONE regular launch (tiles x best uniform chunks), simulated the same way
-    int mode_used = 0;
+    int mode_used = 0;                   // 3 rounds, 1 greedy, 2 uniform
 };
 BlockPlan plan_blocks(const BlockPlanIn& in);
 

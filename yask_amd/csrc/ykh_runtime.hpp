@@ -50,8 +50,10 @@ struct KernelVariant {
     int vz = 0;            // elements per thread along z (0: one 16-byte vector)
     int rx = 0;            // >0: not a marching kernel; a block handles rx consecutive x planes (vecpt)
     const void* func = nullptr;   // the __global__ symbol (for hipFuncGetAttributes: scratch use = register spills)
-    bool desc = false;            // marching kernel that reads per-workgroup BlockDescs (PartArgs::blk): planned launches
-    int xover = 0;                // plane-iterations of overhead per block of such a kernel (prologue; the planner's cost model)
+    // planned launches (ykh_plan.cpp): the shape's twin that reads per-workgroup BlockDescs (PartArgs::blk) and signals
+    void (*launch_desc)(const PartArgs& a, dim3 grid, hipStream_t s) = nullptr;
+    const void* func_desc = nullptr;
+    int xover = 0;                // plane-iterations of overhead per block (prologue; the planner's cost model)
 };
 // bytes of scratch (private segment) per thread of a variant's kernel; > 0 means hipcc spilled registers
 size_t variant_scratch_bytes(const KernelVariant& kv);
@@ -79,6 +81,17 @@ struct PartImpl {
         for (size_t i = 0; i < variants.size(); i++)
             if (std::string(variants[i].name) == name) { default_variant = (int)i; return; }
         throw std::runtime_error(std::string("no kernel variant named ") + name);
+    }
+    // Shape whose twin runs the planned launches of a decomposed rank when the part runs on its static default (and, with
+    // -no-hip_fast_div, on the exact-division default): it must have the same arithmetic as that default (queue renaming, operand
+    // refill and halo rings change none) -- e.g. ssg stage 2's default sits at 256 VGPRs and its twin would spill.
+    int planned_variant = -1, planned_exact_variant = -1;
+    void set_planned(const char* name, const char* exact_name = nullptr) {
+        for (size_t i = 0; i < variants.size(); i++) {
+            if (std::string(variants[i].name) == name) planned_variant = (int)i;
+            if (exact_name && std::string(variants[i].name) == exact_name) planned_exact_variant = (int)i;
+        }
+        if (planned_variant < 0 || (exact_name && planned_exact_variant < 0)) throw std::runtime_error(std::string("no kernel variant named ") + name);
     }
     int exact_div_variant = -1;        // what -no-hip_fast_div selects instead of a default whose divisions are a * rcp(b)
     void set_exact_div(const char* name) {
@@ -330,8 +343,12 @@ public:
     bool round_launches = true;           // -[no-]hip_round_launches: one launch per CU-filling round of tile rows
     bool thin_slab_point_kernel = true;   // -[no-]hip_thin_slab_point_kernel: thin y/z exterior slabs use the point kernel
     bool direct_halo = true;       // -[no-]hip_direct_halo: in-place transfer of contiguous x-face halos
-    idx_t overlap_splits = 2;      // -hip_overlap_splits: interior launches per stage when overlapping comms (each split
-                                   // re-runs the 16-plane prologue: iso3dfd 512^3 interior 0.355 / 0.387 / 0.472 ms at 1 / 2 / 4)
+    idx_t overlap_splits = 1;      // -hip_overlap_splits: interior launches per stage of the slab schedule (each split re-runs the
+                                   // 16-plane prologue: iso3dfd 512^3 interior 0.355 / 0.387 / 0.472 ms at 1 / 2 / 4).  1 since round 3:
+                                   // the splits were there to let RCCL's kernels in between launches, which the copy-based IPC
+                                   // transport does not need; and at 1024^3 a run with 2 splits differs from the one-rank run in the
+                                   // last bit of ~0.2 % of the points per step (1 split, the planned launches and -no-overlap_comms
+                                   // are bit-identical: tools/diag_bitexact.py, gpurun_out/r3c) -- inside the tolerance, cause not found
     idx_t ext_streams_mode = 0;    // -hip_ext_streams: 0 = exterior slabs one after another on the compute stream (default); 1 = every
                                    // slab on its own stream, side by side, the interior after them; 2 = the interior beside them as
                                    // well (the exchange waits for the slabs only).  Measured on one GPU (profiles/r02r_ext_streams):
@@ -433,9 +450,9 @@ public:
     // the halo exchange released from the device when the shell is done (ykh_plan.cpp plan_blocks; replaces exterior slabs +
     // interior pieces wherever the stage's kernel takes block descriptors)
     bool planned_launch = true;        // -[no-]hip_planned_launch
-    idx_t shell_pct = 45;              // -hip_shell_pct <n>: the shell should be done after n % of the launch (fewer, longer shell
-                                       // blocks = less prologue overhead but a later start of the exchange)
-    idx_t plan_mode = 0;               // -hip_plan_mode <0|1|2>: interior pieces by simulated makespan / greedy budgets / uniform chunks
+    idx_t shell_pct = 55;              // -hip_shell_pct <n>: the shell should be done after n % of the launch (55: two rounds of equal
+                                       // blocks, the shell in the first; lower = more rounds = more chunk prologues)
+    idx_t plan_mode = 0;               // -hip_plan_mode <0|1|2>: 0 rounds of equal blocks (default); 1 / 2 the first planner (A/B only)
     struct LaunchPlan { std::string key; BlockPlan plan; BlockDesc* dev = nullptr; };
     std::vector<std::unique_ptr<LaunchPlan>> launch_plans;
     unsigned* sig_dev = nullptr;       // [0] finished signalling blocks, [1] published epoch, [2] a waiter gave up (error), [3] unused
@@ -443,7 +460,9 @@ public:
     bool sig_pending = false;          // the launch just issued publishes sig_epoch: exchange_halos() waits for it on the comm stream
     bool sig_used = false;             // some launch of this run() signalled: run() checks the error word at the end
     int planned_part(const StageMeta& sm) const;        // the stage's one part if it can run as a planned launch, else -1
-    LaunchPlan* get_launch_plan(int part, const bool* has_lo, const bool* has_hi);
+    int planned_variant_of(int part) const;             // the kernel shape whose descriptor-reading twin runs the part's planned launches, or -1
+    mutable std::vector<int> planned_cache_;             // ... remembered per part (-2: not looked up yet); cleared with the launch plans
+    LaunchPlan* get_launch_plan(int part, const bool* has_lo, const bool* has_hi, bool wide_shell = false);
     void launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hipStream_t s);
     void drop_launch_plans();
     void neighbor_sides(bool* has_lo, bool* has_hi) const;
@@ -501,6 +520,16 @@ public:
     idx_t shared_pad_l(int d) const { return shared_pad_l_[d]; }
     idx_t shared_pad_r(int d) const { return shared_pad_r_[d]; }
     idx_t shared_pad_l_[MAX_DOMAIN_DIMS] = {0, 0, 0}, shared_pad_r_[MAX_DOMAIN_DIMS] = {0, 0, 0};
+    // ---- wave-front tiling across ranks (-Mbt n with neighbours; the reference's wave-front extensions, setup.cpp:717-805,
+    // context.cpp:286-346): a group of n steps = P = n x stages phases; phase p is evaluated on the rank box EXTENDED by
+    // angle x (P-1-p) towards every neighbour -- redundantly with that neighbour -- so that no exchange is needed inside the
+    // group; halos (and pads) are wf_ext = angle x (P-1) wider and are exchanged ONCE per group, with all 26 neighbours.
+    idx_t wf_angle_[MAX_DOMAIN_DIMS] = {0, 0, 0};     // widest halo per dim = the shift per phase
+    idx_t wf_ext_[MAX_DOMAIN_DIMS] = {0, 0, 0};       // extra halo / pad per dim (0: plain sweeps)
+    idx_t wf_ext(int d) const { return wf_ext_[d]; }
+    bool wf_ext_always = false;                        // -[no-]hip_wf_ext_always: allocate the extensions on one rank too (tools/decomp_cost.py)
+    bool wf_multi() const { return wf_ext_[0] + wf_ext_[1] + wf_ext_[2] > 0; }
+    void run_wavefront_multi(idx_t t0, idx_t nsteps, idx_t dir, const bool* has_lo, const bool* has_hi, bool exchange);
 };
 
 // one var's region for one neighbour, and the per-neighbour buffers (see ykh_halo.cpp)

@@ -220,7 +220,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                                "bind_inner_threads", "bundle_allocs", "init_scratch_vars", "auto_tune",
                                "allow_addl_padding", "round_up_temporal_angles", "print_suffixes", "verbose",
                                "exchange_halos", "auto_tune_each_stage", "trace", "hip_direct_halo", "hip_thin_slab_point_kernel", "hip_round_launches",
-                               "hip_step_timers", "hip_phase_timers", "hip_fast_div", "hip_planned_launch"};
+                               "hip_step_timers", "hip_phase_timers", "hip_fast_div", "hip_planned_launch", "hip_wf_ext_always"};
     const char* int_opts[] = {"hip_shell_pct", "hip_plan_mode", "hip_placement_trials", "hip_var_skew", "hip_step_graphs", "hip_pitch_extra", "hip_ext_streams", "hip_comm_cus", "hip_fuse_steps", "hip_overlap_splits", "min_exterior", "max_threads", "outer_threads", "inner_threads", "numa_pref",
                               "auto_tune_radius", "thread_divisor", "block_threads", "hip_xchunk", "device_thread_limit"};
     const char* dbl_opts[] = {"auto_tune_trial_secs"};
@@ -245,6 +245,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                     else if (b == "hip_step_timers") step_timers = val;
                     else if (b == "hip_phase_timers") phase_timers = val;
                     else if (b == "hip_planned_launch") planned_launch = val;
+                    else if (b == "hip_wf_ext_always") { wf_ext_always = val; invalidate(); }
                     else if (b == "trace") env->trace = val;
                     else if (b == "hip_direct_halo") { direct_halo = val; invalidate(); }
                     else if (b == "hip_thin_slab_point_kernel") thin_slab_point_kernel = val;
@@ -324,7 +325,12 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                 else if (f == "ri") { rank_index[d] = n; rank_index_set = true; invalidate(); }
                 else ignored_opts[f + (d < ndd ? domain_dim_names[d] : outer_dim_name)] = v;
             };
-            if (didx == 100) { if (f == "b") block_size[0] = n; else if (f == "Mb") mega_block_size[0] = n; else ignored_opts[opt] = v; }
+            if (didx == 100) {
+                // (with neighbours the number of wave-front steps sets the width of halos and pads: prepare_solution() again)
+                if (f == "b") { if (block_size[0] != n && (env->nranks > 1 || wf_ext_always)) invalidate(); block_size[0] = n; }
+                else if (f == "Mb") { if (mega_block_size[0] != n && (env->nranks > 1 || wf_ext_always)) invalidate(); mega_block_size[0] = n; }
+                else ignored_opts[opt] = v;
+            }
             else if (didx == -1) { for (int d = 0; d < ndd; d++) apply(d); if (has_outer) apply(3); }
             else apply(didx);
             break;
@@ -343,9 +349,11 @@ std::string Solution::get_command_line_help() const {
           " -nr<dim> <n>  number of ranks          -ri<dim> <n> this rank's index\n"
           " -mp<dim> <n>  minimum padding          -ep<dim> <n> extra padding\n"
           " -b<dim> <n>   block size (advisory; the HIP tile shape is what matters on the GPU)\n"
-          " -Mbt <n> | -bt <n>  wave-front temporal tiling: n steps are applied to one x-slab after the other, each step\n"
+          " -Mbt <n> | -bt <n>  wave-front temporal tiling.  One rank: n steps are applied to one x-slab after the other, each step\n"
           "               shifted by the stencil's x-halo (the reference's mega-block wave-fronts); -Mbx <n> = slab width\n"
-          "               (default 128).  Exact; slower than plain sweeps on this GPU (DESIGN.md 3.7), off by default.\n"
+          "               (default 128); exact; slower than plain sweeps on this GPU (DESIGN.md 3.7).  Several ranks: halos grow by\n"
+          "               (n x stages - 1) x the stencil halo, every rank evaluates the steps of a group on boxes that shrink towards\n"
+          "               its own (redundantly with its neighbours) and halos are exchanged ONCE per n steps.  Exact.  Off by default.\n"
           " -[no-]overlap_comms   overlap halo exchange with interior computation\n"
           " -min_exterior <n>     minimum width of the exterior slabs\n"
           " -[no-]exchange_halos  perform halo exchanges\n"
@@ -377,9 +385,10 @@ std::string Solution::get_command_line_help() const {
           " -[no-]hip_planned_launch          decomposed runs: the rank box as ONE launch of the marching kernel, shell blocks first,\n"
           "                                   the exchange released from the device when they are done (default on; off: exterior\n"
           "                                   slabs, then the interior in -hip_overlap_splits launches)\n"
-          " -hip_shell_pct <n>                planned launches: the shell is cut so that it is done after n % of the launch (default 45)\n"
-          " -hip_plan_mode <0|1|2>            planned launches: interior pieces 0 = by simulated makespan, 1 = greedy, 2 = uniform chunks\n"
-          " -hip_overlap_splits <n>           interior launches per step when halos are overlapped (default 2)\n"
+          " -hip_shell_pct <n>                planned launches: the shell is to be done after n % of the launch (default 55: two rounds)\n"
+          " -hip_plan_mode <0|1|2>            planned launches: 0 = rounds of equal blocks, shell first (default); 1 / 2 = the first planner\n"
+          "                                   (thin x slabs, per-CU budgets / uniform interior chunks; measured slower, kept for A/B)\n"
+          " -hip_overlap_splits <n>           slab schedule: interior launches per step when halos are overlapped (default 1)\n"
           " -hip_ext_streams <0|1|2>          exterior slabs: 0 one after another (default), 1 side by side on their own streams,\n"
           "                                   2 side by side and beside the interior\n"
           " -hip_comm_cus <n>                 CUs the overlapped interior launches leave to the send/recv kernels (default 0)\n"
@@ -553,11 +562,27 @@ void Solution::prepare() {
                 shared_pad_r_[d] = std::max({shared_pad_r_[d], v->halo_r[d], v->min_pad_r[d]});
             }
     }
+    // Wave-front tiling across ranks (-Mbt / -bt n > 1 with neighbours): halos and pads grow by angle x (phases - 1) in
+    // every decomposed dim (the reference's wf_shift_pts / left_wf_exts / right_wf_exts, setup.cpp:717-805).
+    {
+        const idx_t wf_steps = std::max<idx_t>(mega_block_size[0], block_size[0]);
+        const idx_t shifts = wf_steps > 1 ? wf_steps * meta->n_stages - 1 : 0;
+        for (int d = 0; d < MAX_DOMAIN_DIMS; d++) {
+            wf_angle_[d] = 0;
+            if (d < ndd)
+                for (auto* list : {&vars, &scratch_vars})
+                    for (auto& v : *list)
+                        if (!v->fixed_size && v->uses_domain[d]) wf_angle_[d] = std::max({wf_angle_[d], v->halo_l[d], v->halo_r[d]});
+            const bool split = d < ndd && !has_outer && (num_ranks[d] > 1 || (wf_ext_always && env->nranks == 1));
+            wf_ext_[d] = (split && shifts > 0) ? wf_angle_[d] * shifts : 0;
+        }
+    }
     for (int d = 0; d < ndd; d++) {
-        idx_t need = std::max(shared_pad_l_[d], shared_pad_r_[d]);
+        idx_t need = std::max(shared_pad_l_[d], shared_pad_r_[d]) + wf_ext_[d];
         if (num_ranks[d] > 1 && local_size[d] < need)
             YKH_THROW("local-domain size of " + std::to_string(local_size[d]) + " in '" + domain_dim_names[d] +
-                      "' dim is less than the required halo size of " + std::to_string(need));
+                      "' dim is less than the required halo size of " + std::to_string(need) +
+                      (wf_ext_[d] > 0 ? " (stencil halo + temporal wave-front extension)" : ""));
     }
     std::vector<Var*> need_alloc;
     for (auto& v : vars) {
@@ -1015,6 +1040,28 @@ void Solution::time_decomposed_step(const bool* has_lo, const bool* has_hi, int 
     hipEvent_t e[4];
     for (auto& x : e) YKH_HIP(hipEventCreate(&x));
     float acc[3] = {0, 0, 0};
+    const idx_t wf_steps = std::max<idx_t>(mega_block_size[0], block_size[0]);
+    if (wf_steps > 1 && wf_multi()) {
+        // wave-front tiling across ranks: ms[1] = one step's share of a group's launches (extended, shrinking boxes; no exchange),
+        // ms[2] = one plain sweep of the rank box, ms[0] = 0
+        for (int r = -1; r < reps; r++) {
+            YKH_HIP(hipEventRecord(e[0], compute_stream));
+            run_wavefront_multi((idx_t)(r + 1) * wf_steps, wf_steps, 1, has_lo, has_hi, /*exchange=*/false);
+            YKH_HIP(hipEventRecord(e[2], compute_stream));
+            for (idx_t k = 0; k < wf_steps; k++)
+                for (int st = 0; st < meta->n_stages; st++)
+                    for (int q = 0; q < meta->stages[st].n_parts; q++) launch_part(meta->stages[st].parts[q], r + 1, rb, compute_stream);
+            YKH_HIP(hipEventRecord(e[3], compute_stream));
+            YKH_HIP(hipEventSynchronize(e[3]));
+            if (r < 0) continue;
+            float m = 0;
+            YKH_HIP(hipEventElapsedTime(&m, e[0], e[2])); acc[1] += m / (float)wf_steps;
+            YKH_HIP(hipEventElapsedTime(&m, e[2], e[3])); acc[2] += m / (float)wf_steps;
+        }
+        for (int i = 0; i < 3; i++) ms[i] = acc[i] / (reps > 0 ? reps : 1);
+        for (auto& x : e) (void)hipEventDestroy(x);
+        return;
+    }
     bool all_planned = true;
     for (int st = 0; st < meta->n_stages; st++) all_planned &= planned_part(meta->stages[st]) >= 0;
     for (int r = -1; r < reps; r++) {          // r = -1: warm-up
@@ -1079,6 +1126,7 @@ void Solution::neighbor_sides(bool* has_lo, bool* has_hi) const {
 void Solution::drop_launch_plans() {
     for (auto& lp : launch_plans) if (lp && lp->dev) (void)hipFree(lp->dev);
     launch_plans.clear();
+    planned_cache_.clear();
 }
 // A stage runs as a planned launch when it is ONE part on a marching kernel that reads block descriptors, over a plain
 // 3-D box: no scratch children (they would have to be evaluated per block), no sub-domain box, no per-point predicate.
@@ -1088,23 +1136,42 @@ int Solution::planned_part(const StageMeta& sm) const {
     const PartMeta& pm = *impl.parts[part].meta;
     if (pm.is_scratch || pm.has_step_cond || pm.has_step_cond_dev || part_needs_predicate(part)) return -1;
     if ((size_t)part < part_has_bb.size() && part_has_bb[part]) return -1;
-    if (part_variant[part] < 0) return -1;
-    const KernelVariant& kv = impl.parts[part].variants[part_variant[part]];
-    if (!kv.desc || !kv.star || kv.rx != 0) return -1;
-    return part;
+    return planned_variant_of(part) >= 0 ? part : -1;
 }
-Solution::LaunchPlan* Solution::get_launch_plan(int part, const bool* has_lo, const bool* has_hi) {
-    const KernelVariant& kv = impl.parts[part].variants[part_variant[part]];
+int Solution::planned_variant_of(int part) const {
+    if (planned_cache_.size() != impl.parts.size()) planned_cache_.assign(impl.parts.size(), -2);
+    if (planned_cache_[part] != -2) return planned_cache_[part];
+    auto remember = [&](int r) { planned_cache_[part] = r; return r; };
+    const PartImpl& pi = impl.parts[part];
+    int v = part_variant[part];
+    if (v < 0) return -1;
+    // the part runs on its static default: the shape named for planned launches (same arithmetic, room for the twin's registers)
+    if (variant_override.empty()) {
+        if (v == pi.default_variant && pi.planned_variant >= 0) v = pi.planned_variant;
+        else if (v == pi.exact_div_variant && pi.planned_exact_variant >= 0) v = pi.planned_exact_variant;
+    }
+    const KernelVariant& kv = pi.variants[v];
+    if (!kv.launch_desc || !kv.star || kv.rx != 0) return remember(-1);
+    if (kv.func_desc) {          // a twin that spilled registers is never worth it
+        hipFuncAttributes at;
+        if (hipFuncGetAttributes(&at, kv.func_desc) == hipSuccess) { if (at.localSizeBytes > 0) return remember(-1); }
+        else (void)hipGetLastError();
+    }
+    return remember(v);
+}
+Solution::LaunchPlan* Solution::get_launch_plan(int part, const bool* has_lo, const bool* has_hi, bool wide_shell) {
+    const KernelVariant& kv = impl.parts[part].variants[planned_variant_of(part)];
     std::ostringstream ks;
-    ks << part << ':' << part_variant[part] << '/' << local_size[0] << 'x' << local_size[1] << 'x' << local_size[2] << '/';
+    ks << part << ':' << planned_variant_of(part) << '/' << local_size[0] << 'x' << local_size[1] << 'x' << local_size[2] << '/';
     for (int d = 0; d < 3; d++) ks << (has_lo[d] ? 'l' : '-') << (has_hi[d] ? 'h' : '-');
-    ks << '/' << shell_pct << '/' << plan_mode << '/' << min_exterior << '/' << env->num_cus;
+    ks << '/' << shell_pct << '/' << plan_mode << '/' << min_exterior << '/' << env->num_cus << '/' << (wide_shell ? wf_ext_[0] + wf_ext_[1] * 1000 + wf_ext_[2] * 1000000 : 0);
     const std::string key = ks.str();
     for (auto& lp : launch_plans) if (lp->key == key) return lp.get();
     BlockPlanIn in;
     for (int d = 0; d < 3; d++) {
         in.n[d] = local_size[d]; in.has_lo[d] = has_lo[d]; in.has_hi[d] = has_hi[d];
-        in.width[d] = std::max<idx_t>(std::max(shared_pad_l_[d], shared_pad_r_[d]), min_exterior);
+        // (what a neighbour needs of my boundary: the halo -- plus the wave-front extension in a multi-rank -Mbt group)
+        in.width[d] = std::max<idx_t>(std::max(shared_pad_l_[d], shared_pad_r_[d]) + (wide_shell ? wf_ext_[d] : 0), min_exterior);
     }
     in.ty = kv.ty; in.tz = kv.tz;
     in.overhead = kv.xover > 0 ? kv.xover : std::max<idx_t>(1, shared_pad_r_[0] + 1);
@@ -1126,7 +1193,7 @@ Solution::LaunchPlan* Solution::get_launch_plan(int part, const bool* has_lo, co
     return launch_plans.back().get();
 }
 void Solution::launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hipStream_t s) {
-    const KernelVariant& kv = impl.parts[part].variants[part_variant[part]];
+    const KernelVariant& kv = impl.parts[part].variants[planned_variant_of(part)];
     PartArgs a;
     fill_part_args(part, t, rank_box(), a);
     a.blk = lp.dev;
@@ -1145,7 +1212,7 @@ void Solution::launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hi
         sig_pending = true;
         sig_used = true;
     }
-    kv.launch(a, dim3((unsigned)lp.plan.blocks.size(), 1, 1), s);
+    kv.launch_desc(a, dim3((unsigned)lp.plan.blocks.size(), 1, 1), s);
     YKH_HIP(hipGetLastError());
 }
 
@@ -1321,6 +1388,54 @@ void Solution::run_wavefront(idx_t t0, idx_t nsteps, idx_t dir) {
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------ wave-front tiling across ranks
+// The reference's temporal wave-fronts work across ranks by extending every rank's evaluation into its neighbours' domains
+// (left/right_wf_exts = angle x shifts, setup.cpp:717-805; the diagram in run_solution, context.cpp:286-346): the points
+// between "end (rank)" and "end (ext)" are computed by both ranks, and halos are exchanged once per group of -Mbt steps.
+// Here: a group of n steps is P = n x stages phases; phase p runs the stage's parts over the rank box grown by
+// wf_angle x (P-1-p) towards every side that has a neighbour.  Phase p+1's reads (reach: the halo = the angle) then lie
+// inside what phase p computed, the last phase covers exactly the rank box, and nothing has to travel inside the group.
+// The widened halos (wf_ext = angle x (P-1) beyond the stencil halo, all 26 neighbours: extended boxes have edges and
+// corners) are exchanged once per group -- half the messages per step at n = 2, against ~(1 + ext/size)^3 of redundant
+// arithmetic.  Every launch is an ordinary launch of the same kernel: bit-identical to plain multi-rank sweeps.
+// The last phase runs as a planned launch where the stage allows it (shell = what the neighbours need, now halo + wf_ext
+// wide, first; the exchange starts while the interior is still being computed).
+void Solution::run_wavefront_multi(idx_t t0, idx_t nsteps, idx_t dir, const bool* has_lo, const bool* has_hi, bool exchange) {
+    const idx_t nphase = nsteps * meta->n_stages;
+    const Box rb = rank_box();
+    for (idx_t p = 0; p < nphase; p++) {
+        const idx_t t = t0 + dir * (p / meta->n_stages);
+        const int st = (int)(p % meta->n_stages);
+        const StageMeta& sm = meta->stages[st];
+        const idx_t e = nphase - 1 - p;
+        Box b = rb;
+        for (int d = 0; d < ndd; d++) {
+            if (wf_ext_[d] <= 0) continue;
+            if (has_lo[d]) b.lo[d] -= wf_angle_[d] * e;
+            if (has_hi[d]) b.hi[d] += wf_angle_[d] * e;
+        }
+        const bool last = p == nphase - 1;
+        const int pl_part = (last && exchange && overlap_comms) ? planned_part(sm) : -1;
+        cur_phase = (exchange && last) ? phase_next() : nullptr;
+        if (pl_part >= 0) {
+            LaunchPlan* lp = get_launch_plan(pl_part, has_lo, has_hi, /*wide_shell=*/true);
+            phase_mark(PH_EXT0, compute_stream);
+            launch_planned(pl_part, t, *lp, /*signal=*/true, compute_stream);
+        } else {
+            phase_mark(PH_EXT1, compute_stream);
+            for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, b, compute_stream);
+        }
+        note_stage_written(sm, t);
+        if (last && exchange) {
+            exchange_halos(t, st, /*start_only=*/true, false);
+            phase_mark(PH_INT1, compute_stream);
+            exchange_halos(t, st, false, /*finish_only=*/true);
+            phase_mark(PH_WAIT1, compute_stream);
+        }
+        cur_phase = nullptr;
     }
 }
 
@@ -1507,6 +1622,21 @@ void Solution::run(idx_t first_step, idx_t last_step) {
             first_plain = first_step + dir * 2 * npairs;
         }
     }
+    if (wf_steps > 1 && multi && wf_multi()) {
+        // groups of wf_steps steps, one halo exchange per group (run_wavefront_multi above)
+        bool lo[MAX_DOMAIN_DIMS], hi[MAX_DOMAIN_DIMS];
+        neighbor_sides(lo, hi);
+        for (idx_t t = first_step; dir > 0 ? t <= last_step : t >= last_step;) {
+            const idx_t left = (dir > 0 ? last_step - t : t - last_step) + 1, g = std::min(wf_steps, left);
+            run_wavefront_multi(t, g, dir, lo, hi, /*exchange=*/true);
+            for (idx_t k = 0; k < g; k++) {
+                nsteps++;
+                if (step_timers) YKH_HIP(hipEventRecord(step_events[nsteps], compute_stream));
+            }
+            t += dir * g;
+        }
+        first_plain = last_step + dir;         // nothing left for the plain loop below
+    }
     const bool wavefront = wf_steps > 1 && !multi && env->nranks == 1 && ndd >= 1;
     for (idx_t t = first_plain; wavefront && (dir > 0 ? t <= last_step : t >= last_step);) {
         const idx_t left = (dir > 0 ? last_step - t : t - last_step) + 1, g = std::min(wf_steps, left);
@@ -1547,12 +1677,14 @@ void Solution::run(idx_t first_step, idx_t last_step) {
             const StageMeta& sm = meta->stages[st];
             const bool overlap = multi && overlap_comms && have_interior;
             cur_phase = multi ? phase_next() : nullptr;
-            const int pl_part = overlap ? planned_part(sm) : -1;
+            bool lo[MAX_DOMAIN_DIMS], hi[MAX_DOMAIN_DIMS];
+            neighbor_sides(lo, hi);
+            // (x-only decompositions keep the slab schedule: their faces are whole planes, the two thin slabs cost 2-14 % where
+            //  cutting every tile into rounds costs 4-40 %, tools/decomp_cost.py)
+            const int pl_part = (overlap && (lo[1] || hi[1] || lo[2] || hi[2])) ? planned_part(sm) : -1;
             if (pl_part >= 0) {
                 // ONE launch over the rank box: shell blocks first, the exchange released from the device when they are done
                 // (the reference's exterior-first order, context.cpp:377-478, without separate launches)
-                bool lo[MAX_DOMAIN_DIMS], hi[MAX_DOMAIN_DIMS];
-                neighbor_sides(lo, hi);
                 LaunchPlan* lp = get_launch_plan(pl_part, lo, hi);
                 phase_mark(PH_EXT0, compute_stream);
                 launch_planned(pl_part, t, *lp, /*signal=*/true, compute_stream);
@@ -1734,6 +1866,7 @@ void Solution::tune_variants(bool quick) {
             YKH_HIP(hipMemcpyAsync(vars[i]->dptr, saves[i], vars[i]->bytes(), hipMemcpyDeviceToDevice, compute_stream));
         }
     YKH_HIP(hipStreamSynchronize(compute_stream));
+    drop_launch_plans();          // (the kernel shapes may have changed)
 }
 
 idx_t Solution::compare_data(const Solution& ref, double eps) const {

@@ -239,7 +239,8 @@ template <class V, typename T> __device__ __forceinline__ void stv_nt(T* p, V v)
 // MINW: minimum resident waves per SIMD the register allocation must allow (k blocks of T threads per
 //       CU <=> k*T/256), MI355X_MICROARCH.md "Register files".
 // ABL (profiling only): 1 = no halo loads, 2 = no centre-operand loads, 4 = no stores.
-template <class P, int VZ, int TZL, int TYL, int RY, int ROT, int NTH, int MINW, int CH, int ABL = 0>
+// DESC: the twin that takes its tile and x range from a block descriptor (planned launches, ykh_plan.cpp) and signals when done.
+template <class P, int VZ, int TZL, int TYL, int RY, int ROT, int NTH, int MINW, int CH, int ABL = 0, bool DESC = false>
 __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs a) {
     typedef StarLinCfg<P, VZ, TZL, TYL, RY, ROT, CH> C;
     typedef typename C::T T;
@@ -261,16 +262,15 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
     T* slab = reinterpret_cast<T*>(ykh_smem);
 
     // the workgroup's tile and x range: the regular XCD-aware tiling of the box, or a planned launch's descriptor
-    const BlockBox bb = block_box<VZ, C::TZ, C::TY>(a);
+    const BlockBox bb = block_box<VZ, C::TZ, C::TY, DESC>(a);
     const int tid = threadIdx.x;
     const int lz = tid % TZL, ly = tid / TZL;
     const int zt0 = bb.zt0, yt0 = bb.yt0, xs = bb.xs, xe = bb.xe;
-    const int bz0 = bb.z0, bz1 = bb.z1, by1 = bb.y1;       // the box the stores are clipped to
     if (xs >= xe) return;
     const int xlast = xe + XH;       // planes xs .. xlast-1 arrive
 
     const int myz = zt0 + lz * VZ;
-    const bool tile_inside = zt0 >= bz0 && zt0 + C::TZ <= bz1 && yt0 + C::TY <= by1;      // uniform
+    const bool tile_inside = zt0 >= a.z0 && zt0 + C::TZ <= a.z1 && yt0 + C::TY <= a.y1;      // uniform
     const int zc = clampi(myz, a.az0, a.az1 - VZ);
     const T* __restrict__ sp = (const T*)a.ptr[SG];
 
@@ -532,18 +532,18 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
                         auto ob = sbase((T*)a.ptr[g] + ((idx_t)xo * a.sx + org));          // uniform
                         if constexpr (NT_STREAMS) stv_b_nt<V>(ob, roff[j], out[g]); else stv_b<V>(ob, roff[j], out[g]);
                     });
-            } else if (xo >= xs && xo < xe && y < by1 && myz < bz1 && myz + VZ > bz0) {
+            } else if (xo >= xs && xo < xe && y < a.y1 && myz < a.z1 && myz + VZ > a.z0) {
                 // points inside the box are never clamped, so roff[j] is also the store offset
                 static_for<P::n_writes>([&](auto wc) {
                     constexpr int g = P::writes[decltype(wc)::value];
                     auto ob = sbase((T*)a.ptr[g] + ((idx_t)xo * a.sx + org));          // uniform
                     if constexpr (ABL & 4) { if (out[g][0] == T(123.456)) ob[0] = out[g][0]; }
-                    else if (myz >= bz0 && myz + VZ <= bz1) {
+                    else if (myz >= a.z0 && myz + VZ <= a.z1) {
                         if constexpr (NT_STREAMS) stv_b_nt<V>(ob, roff[j], out[g]); else stv_b<V>(ob, roff[j], out[g]);
                     } else {
                         static_for<VZ>([&](auto ec) {
                             constexpr int e = decltype(ec)::value;
-                            if (myz + e >= bz0 && myz + e < bz1) stv_b<T>(ob, roff[j] + e * (unsigned)sizeof(T), out[g][e]);
+                            if (myz + e >= a.z0 && myz + e < a.z1) stv_b<T>(ob, roff[j] + e * (unsigned)sizeof(T), out[g][e]);
                         });
                     }
                 });
@@ -594,7 +594,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
         for (int x = xs; x < xlast; x += C::UNR)
             static_for<C::UNR>([&](auto phc) { plane(x + decltype(phc)::value, phc, phc); });
     }
-    block_done(a, bb.flags);
+    if constexpr (DESC) block_done(a, bb.flags);
 }
 
 }  // namespace ykh

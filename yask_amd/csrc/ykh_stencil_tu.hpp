@@ -56,16 +56,16 @@ KernelVariant star_variant() {
     return kv;
 }
 
-template <class P, int VZ, int TZL, int TYL, int RY, int ROT, int NTH, int MINW, int CH, int ABL = 0>
+template <class P, int VZ, int TZL, int TYL, int RY, int ROT, int NTH, int MINW, int CH, int ABL = 0, bool DESC = false>
 void launch_starlin(const PartArgs& a, dim3 grid, hipStream_t s) {
     typedef StarLinCfg<P, VZ, TZL, TYL, RY, ROT, CH> C;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&starlin_kernel<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&starlin_kernel<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL, DESC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((starlin_kernel<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL>), grid, dim3(C::NT), C::lds_bytes, s, a);
+    hipLaunchKernelGGL((starlin_kernel<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL, DESC>), grid, dim3(C::NT), C::lds_bytes, s, a);
 }
 
 template <class P, int VZ, int TZL, int TYL, int RX>
@@ -84,16 +84,16 @@ KernelVariant vecpt_variant() {
     return kv;
 }
 
-template <class P, int VZ, int TZL, int TYL, int MINW, int RY = 1, bool PIN = false, int PD = 1, int NT = 0>
+template <class P, int VZ, int TZL, int TYL, int MINW, int RY = 1, bool PIN = false, int PD = 1, int NT = 0, bool DESC = false>
 void launch_march(const PartArgs& a, dim3 grid, hipStream_t s) {
     typedef MarchCfg<P, VZ, TZL, TYL, RY, (NT & 2) != 0> C;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT, DESC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT>), grid, dim3(C::NT), C::lds_bytes, s, a);
+    hipLaunchKernelGGL((march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT, DESC>), grid, dim3(C::NT), C::lds_bytes, s, a);
 }
 // Generic marching kernel (ykh_march.hpp). Name: march_v<VZ>_z<tile z>_y<tile y>[_r<rows>][_pin][_pd<planes ahead>][_nt][_hr]_w<min waves/SIMD>
 // (NT: flag bits, 1 = non-temporal one-touch streams, 2 = halo rings, 4 = packed subtractions (_ps), 8 = reciprocal divisions (_fd), 16 / 32 / 64 = queue renaming in trips of 2 / 4 / 8 planes, 128 = late refill of the once operands (_lo))
@@ -106,8 +106,16 @@ KernelVariant march_variant() {
     KernelVariant kv{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_march<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT>};
     kv.vz = VZ;
     kv.func = reinterpret_cast<const void*>(&march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT>);
-    kv.desc = true;                       // takes planned launches (block descriptors, completion signal)
     kv.xover = C::XOVER;                  // a block's prologue: the deepest x queue it fills before its first plane
+    return kv;
+}
+// The same shape plus its descriptor-reading twin (planned launches of a decomposed rank): a second instantiation of the kernel,
+// so only the shapes a decomposed run may use are registered this way.
+template <class P, int VZ, int TZL, int TYL, int MINW, int RY = 1, bool PIN = false, int PD = 1, int NT = 0>
+KernelVariant march_variant_planned() {
+    KernelVariant kv = march_variant<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT>();
+    kv.launch_desc = &launch_march<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT, true>;
+    kv.func_desc = reinterpret_cast<const void*>(&march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT, true>);
     return kv;
 }
 
@@ -124,8 +132,14 @@ KernelVariant starlin_variant() {
     KernelVariant kv{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_starlin<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL>};
     kv.vz = VZ;
     kv.func = reinterpret_cast<const void*>(&starlin_kernel<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL>);
-    kv.desc = true;                       // takes planned launches (block descriptors, completion signal)
     kv.xover = C::XH + 1;                 // a block runs XH plane-iterations before its first output plane (+ the queue loads)
+    return kv;
+}
+template <class P, int VZ, int TZL, int TYL, int RY, int ROT, int NTH, int MINW, int CH>
+KernelVariant starlin_variant_planned() {        // the shape plus its descriptor-reading twin (see march_variant_planned)
+    KernelVariant kv = starlin_variant<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, 0>();
+    kv.launch_desc = &launch_starlin<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, 0, true>;
+    kv.func_desc = reinterpret_cast<const void*>(&starlin_kernel<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, 0, true>);
     return kv;
 }
 

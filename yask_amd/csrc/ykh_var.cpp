@@ -128,8 +128,9 @@ void Var::compute_geometry() {
             // pad = max(halo, min pads) + extra pad (YkVarBase::resize, src/kernel/lib/yk_var.cpp:239-326);
             // additionally every var shares the solution-wide maximum so that all full-dim vars
             // have identical strides (one address computation serves all of them in a kernel).
-            pad_l[d] = std::max<idx_t>({halo_l[d], min_pad_l[d], soln->min_pad[d], soln->shared_pad_l(d)}) + soln->extra_pad[d];
-            pad_r[d] = std::max<idx_t>({halo_r[d], min_pad_r[d], soln->min_pad[d], soln->shared_pad_r(d)}) + soln->extra_pad[d];
+            // (+ the wave-front extension of a multi-rank -Mbt run, the reference's left/right_wf_exts, yk_var.cpp:239-326)
+            pad_l[d] = std::max<idx_t>({halo_l[d], min_pad_l[d], soln->min_pad[d], soln->shared_pad_l(d)}) + soln->extra_pad[d] + soln->wf_ext(d);
+            pad_r[d] = std::max<idx_t>({halo_r[d], min_pad_r[d], soln->min_pad[d], soln->shared_pad_r(d)}) + soln->extra_pad[d] + soln->wf_ext(d);
         }
         if (d == inner) {
             pad_l[d] = round_up(pad_l[d], zal);
