@@ -91,6 +91,11 @@ int yk_env_init_tcp(yk_env_h env, int rank, int num_ranks, const char* addr, int
  * MPI requests during the interior (adv_halo_exchange, src/kernel/lib/halo.cpp:494-574).  Ranks may share a device (tests).
  * Control messages and the scalar all-reduce run over the same TCP mesh as yk_env_init_tcp(). YASK_HIP_TRANSPORT=ipc. */
 int yk_env_init_ipc(yk_env_h env, int rank, int num_ranks, const char* addr, int base_port);
+/* Timing instrument, not a transport: this ONE process plays rank `rank` of `num_ranks`; what it sends to a neighbour comes back
+ * as what it expects from that neighbour (a device-to-device copy on the communication stream; the halo DATA are therefore those
+ * of a reflecting boundary).  Runs the full launch / pack / copy / unpack / wait schedule of a decomposed job's rank on one GPU:
+ * tools/overlap_probe.py measures with it how much of the exchange each schedule hides. */
+int yk_env_init_mirror(yk_env_h env, int rank, int num_ranks);
 /* that mesh alone (no GPU needed): connect, one SUM all-reduce of the ranks over it, close; 0 on success */
 int yk_tcp_mesh_check(int rank, int num_ranks, const char* addr, int base_port, long long* sum);
 /* the rendezvous alone (no GPU needed): rank 0 serves `nbytes` of `buf` to the other ranks; 0 on success */

@@ -1,0 +1,91 @@
+#!/usr/bin/env python
+"""GPU box (one GPU): how much of the halo exchange does each step schedule hide?
+
+One process plays a rank of a decomposed job through the mirror transport (yk_env_init_mirror: what it sends to a neighbour comes
+back as what it expects from that neighbour -- a device-to-device copy on the communication stream, the stand-in for an equally
+fast peer; halo DATA are those of a reflecting boundary, so this measures time, not values).  The full schedule runs: planned
+launch (or slabs + interior, or the whole box), device-side signal, pack kernels, copy, unpack kernels, the compute stream's wait.
+Reported per step (HIP events of yk_stats): exterior / interior / pack / transport / unpack / exposed wait, ms per step, and
+the undivided single-rank step for reference.
+    python tools/overlap_probe.py [--stencil iso3dfd]"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+
+CASES = {  # name -> (global size, rank grid, rank played)
+    "iso3dfd": [("c2 / 8 GPUs 2x2x2: 512^3 block, 3 face neighbours", (1024, 1024, 1024), (2, 2, 2), 0),
+                ("c4 / 8 GPUs 2x2x2: 1024x1024x512 block", (2048, 2048, 1024), (2, 2, 2), 0),
+                ("c2 / 4 GPUs 2x2x1: 512x512x1024 block", (1024, 1024, 1024), (2, 2, 1), 0)],
+    "ssg": [("ssg 1024^3 / 8 GPUs 2x2x2: 512^3 block", (1024, 1024, 1024), (2, 2, 2), 0),
+            ("ssg 512^3 / 8 GPUs 2x2x2: 256^3 block", (512, 512, 512), (2, 2, 2), 0)],
+}
+SCHEDULES = [("planned (rounds, shell first)", "-overlap_comms -hip_planned_launch"),
+             ("planned, shell by 35 %", "-overlap_comms -hip_planned_launch -hip_shell_pct 35"),
+             ("slabs + interior (round 2)", "-overlap_comms -no-hip_planned_launch"),
+             ("whole box, then exchange", "-no-overlap_comms")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stencil", default="iso3dfd")
+    ap.add_argument("--steps", type=int, default=40)
+    args = ap.parse_args()
+    from yask_amd import yk_factory
+    from yask_amd.kernel import yk_env
+    yk_env.disable_debug_output()
+    fac = yk_factory(args.stencil)
+    out = []
+    for name, g, nr, rank in CASES[args.stencil]:
+        world = nr[0] * nr[1] * nr[2]
+        local = [g[d] // nr[d] for d in range(3)]
+        # reference: the same block as a one-rank job
+        s = fac.new_solution(fac.new_env())
+        s.set_overall_domain_size_vec(local)
+        assert s.apply_command_line_options("-no-auto_tune") == ""
+        s.prepare_solution()
+        for k, v in enumerate(s.get_vars()):
+            v.set_elements_hash(1.0, 0.1, hash_id=k)
+        s.run_solution(0, 9)
+        t0 = time.perf_counter()
+        s.run_solution(10, 10 + args.steps - 1)
+        one_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        s.end_solution()
+        for label, opts in SCHEDULES:
+            env = fac.new_env()
+            env.init_mirror(rank, world)
+            s = fac.new_solution(env)
+            s.set_overall_domain_size_vec(list(g))
+            s.set_num_ranks_vec(list(nr))
+            assert s.apply_command_line_options("-no-auto_tune " + opts) == ""
+            s.prepare_solution()
+            for k, v in enumerate(s.get_vars()):
+                v.set_elements_hash(1.0, 0.1, hash_id=k)
+            s.run_solution(0, 9)
+            s.get_stats()
+            t0 = time.perf_counter()
+            s.run_solution(10, 10 + args.steps - 1)
+            ms = (time.perf_counter() - t0) / args.steps * 1e3
+            st = s.get_stats()
+            n = args.steps
+            comm = st.get_halo_pack_secs() + st.get_halo_xfer_secs() + st.get_halo_unpack_secs()
+            rec = {"case": name, "schedule": label, "ms_per_step": round(ms, 4), "one_rank_block_ms_per_step": round(one_ms, 4),
+                   "vs_one_rank_block": round(ms / one_ms, 3),
+                   "exterior_ms": round(st.get_exterior_secs() / n * 1e3, 4), "interior_ms": round(st.get_interior_secs() / n * 1e3, 4),
+                   "pack_ms": round(st.get_halo_pack_secs() / n * 1e3, 4), "copy_ms": round(st.get_halo_xfer_secs() / n * 1e3, 4),
+                   "unpack_ms": round(st.get_halo_unpack_secs() / n * 1e3, 4), "exposed_wait_ms": round(st.get_halo_wait_secs() / n * 1e3, 4),
+                   "comm_hidden_fraction": round(max(0.0, 1.0 - st.get_halo_wait_secs() / comm), 3) if comm > 0 else None,
+                   "halo_MB_per_step": round(st.get_halo_bytes_sent() / n / 1e6, 2)}
+            out.append(rec)
+            print(json.dumps(rec), flush=True)
+            s.end_solution()
+    od = Path(__file__).resolve().parents[1] / "gpurun_out"
+    od.mkdir(exist_ok=True)
+    json.dump(out, open(od / f"overlap_probe_{args.stencil}.json", "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "yk_env_init_from_launcher": (C.c_int, [_H]),
     "yk_env_init_tcp": (C.c_int, [_H, C.c_int, C.c_int, _S, C.c_int]),
     "yk_env_init_ipc": (C.c_int, [_H, C.c_int, C.c_int, _S, C.c_int]),
+    "yk_env_init_mirror": (C.c_int, [_H, C.c_int, C.c_int]),
     "yk_rendezvous_bcast": (C.c_int, [C.c_int, C.c_int, _S, C.c_int, C.c_void_p, C.c_size_t]),
     "yk_tcp_mesh_check": (C.c_int, [C.c_int, C.c_int, _S, C.c_int, C.POINTER(C.c_longlong)]),
     "yk_env_transport_loopback": (C.c_int, [_H, C.c_size_t]),

@@ -84,15 +84,16 @@ void Solution::free_halo_buffers() {
     xfers.clear();
 }
 
-// Copy every dirty (var, slot) slab of `slabs` between the vars and the contiguous buffer.
-static size_t move_slabs(Solution& s, const std::vector<Slab>& slabs, void* buf, bool pack, hipStream_t st) {
+// Every dirty (var, slot) slab of `slabs`, laid out one after the other in the contiguous buffer: appended to `segs`
+// (launch_halo_move moves all segments of an exchange in one launch); returns the bytes of the message.
+static size_t collect_slabs(Solution& s, const std::vector<Slab>& slabs, void* buf, std::vector<HaloSeg>& segs) {
     size_t ofs = 0;
     const int eb = s.elem_bytes();
     for (const Slab& sl : slabs) {
         Var& v = *s.vars[sl.var];
         for (int slot = 0; slot < v.nslots; slot++) {
             if (!v.dirty[slot]) continue;
-            // misc indices are laid out outside the domain dims: copy each misc plane
+            // misc indices are laid out outside the domain dims: one segment per misc plane
             std::vector<idx_t> mofs = {0};
             for (size_t p = 0; p < v.dims.size(); p++) {
                 if (v.dims[p].type != DIM_MISC) continue;
@@ -102,15 +103,12 @@ static size_t move_slabs(Solution& s, const std::vector<Slab>& slabs, void* buf,
                 mofs.swap(nxt);
             }
             for (idx_t mo : mofs) {
-                BoxCopyArgs a{};
-                a.var_elem_bytes = a.buf_elem_bytes = eb;
-                a.var_base = (char*)v.dptr + ((size_t)slot * v.slot_elems + v.origin_elems + mo) * eb;
-                a.sx = v.stride[0]; a.sy = v.stride[1]; a.sz = v.stride[2];
-                for (int d = 0; d < 3; d++) { a.lo[d] = sl.lo[d]; a.n[d] = sl.n[d]; }
-                a.bs[2] = 1; a.bs[1] = sl.n[2]; a.bs[0] = sl.n[1] * sl.n[2];
-                a.buf = (char*)buf + ofs;
-                if (pack) launch_box_gather(a, st);
-                else launch_box_scatter(a, st);
+                HaloSeg h;
+                h.var_base = (char*)v.dptr + ((size_t)slot * v.slot_elems + v.origin_elems + mo) * eb;
+                h.buf = (char*)buf + ofs;
+                h.sx = v.stride[0]; h.sy = v.stride[1]; h.sz = v.stride[2];
+                for (int d = 0; d < 3; d++) { h.lo[d] = (int)sl.lo[d]; h.n[d] = (int)sl.n[d]; }
+                segs.push_back(h);
                 ofs += (size_t)(sl.n[0] * sl.n[1] * sl.n[2]) * eb;
             }
         }
@@ -145,6 +143,7 @@ void Solution::exchange_halos(idx_t /*t_written*/, int /*stage*/, bool start_onl
             YKH_HIP(hipStreamWaitEvent(comm_stream, ev_a, 0));
         }
         phase_mark(PH_PACK0, comm_stream);
+        std::vector<HaloSeg> segs;
         for (auto& x : xfers) {
             if (x->direct) {
                 // one message per dirty (var, slot): whole planes (with their y/z pads) straight from / into the var
@@ -169,7 +168,7 @@ void Solution::exchange_halos(idx_t /*t_written*/, int /*stage*/, bool start_onl
                 }
                 continue;
             }
-            x->send_now = move_slabs(*this, x->send, x->send_buf, true, comm_stream);
+            x->send_now = collect_slabs(*this, x->send, x->send_buf, segs);
             // receive size: same rule evaluated on my recv slabs (neighbour's dirty flags mirror mine)
             size_t r = 0;
             for (const Slab& sl : x->recv) {
@@ -187,6 +186,7 @@ void Solution::exchange_halos(idx_t /*t_written*/, int /*stage*/, bool start_onl
             m.tag = (x->nb.ofs[0] + 1) * 9 + (x->nb.ofs[1] + 1) * 3 + (x->nb.ofs[2] + 1);
             msgs.push_back(m);
         }
+        launch_halo_move(segs, /*pack=*/true, elem_bytes(), comm_stream);
         phase_mark(PH_PACK1, comm_stream);
         for (const HaloMsg& m : msgs) {
             stats.halo_bytes_sent += (idx_t)m.send_bytes; stats.halo_bytes_recv += (idx_t)m.recv_bytes;
@@ -200,8 +200,10 @@ void Solution::exchange_halos(idx_t /*t_written*/, int /*stage*/, bool start_onl
         if (env->exch_wait && env->exch_wait(env->user, (int)msgs.size(), msgs.data(), (void*)comm_stream) != 0)
             YKH_THROW("halo-exchange transport failed while waiting");
         phase_mark(PH_XFER1, comm_stream);
+        std::vector<HaloSeg> segs;
         for (auto& x : xfers)
-            if (x->recv_now && !x->direct) move_slabs(*this, x->recv, x->recv_buf, false, comm_stream);
+            if (x->recv_now && !x->direct) collect_slabs(*this, x->recv, x->recv_buf, segs);
+        launch_halo_move(segs, /*pack=*/false, elem_bytes(), comm_stream);
         phase_mark(PH_UNPACK1, comm_stream);
         YKH_HIP(hipEventRecord(ev_b, comm_stream));
         YKH_HIP(hipStreamWaitEvent(compute_stream, ev_b, 0));

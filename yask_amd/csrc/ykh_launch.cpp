@@ -19,6 +19,7 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <chrono>
 #include <cstdlib>
@@ -360,6 +361,33 @@ int yk_tcp_mesh_check(int rank, int nranks, const char* addr, int base_port, lon
     for (int fd : st->fd) if (fd >= 0) ::close(fd);
     delete st;
     return rc;
+}
+
+// "Mirror" transport: ONE process plays rank `rank` of `nranks`; every message it sends to a neighbour comes back as the message
+// it expects FROM that neighbour (device-to-device copy of its own send buffer on the communication stream).  The halo DATA are
+// wrong by construction (a reflecting boundary) -- this is a timing instrument, not a transport: it lets one GPU run the exact
+// launch / pack / copy / unpack / wait schedule of a rank of a decomposed job with an equally fast neighbour, so that what the
+// schedule hides of the exchange can be measured without a second GPU (tools/overlap_probe.py).
+int yk_env_init_mirror(yk_env_h e, int rank, int nranks) {
+    try {
+        if (!e) return 1;
+        e->env->set_ranks(rank, nranks);
+        e->env->exch_start = [](void*, int n, const ykh::HaloMsg* m, void* stream) -> int {
+            for (int i = 0; i < n; i++) {
+                const size_t nb = std::min(m[i].send_bytes, m[i].recv_bytes);
+                if (nb && hipMemcpyAsync(m[i].recv_buf, m[i].send_buf, nb, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return 1;
+            }
+            return 0;
+        };
+        e->env->exch_wait = [](void*, int, const ykh::HaloMsg*, void*) -> int { return 0; };
+        e->env->allreduce = [](void*, int, long long*) -> int { return 0; };       // every rank would report what this one does
+        e->env->exch_reset = nullptr;
+        e->env->exch_check = nullptr;
+        if (e->env->user && e->env->user_free) e->env->user_free(e->env->user);
+        e->env->user = nullptr;
+        e->env->user_free = nullptr;
+        return 0;
+    } catch (...) { return 1; }
 }
 
 int yk_env_init_from_launcher(yk_env_h e) {

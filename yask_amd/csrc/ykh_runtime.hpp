@@ -572,6 +572,17 @@ struct BoxCopyArgs {
     idx_t bs[3];          // buffer strides (elements) for box dims x,y,z
     int var_elem_bytes, buf_elem_bytes;
 };
+// Halo pack / unpack (ykh_util_kernels.hip): ALL slabs of an exchange -- every neighbour, var, step slot, misc index -- move
+// in one launch per ~40 segments; a thread moves one 16-byte vector (or one element where a slab's z extent / alignment does not
+// allow vectors) of the packed buffer, so every lane is busy whatever the slab's shape (round 2's per-slab kernels put 256
+// lanes on the 8 points of a z-face row: 0.25 ms to pack 29 MB beside a running stencil, tools/overlap_probe.py).
+struct HaloSeg {
+    void* var_base;       // address of local element (0,0,0) of the slot (+misc offset)
+    void* buf;            // where the segment starts in the packed message
+    idx_t sx, sy, sz;     // var strides (elements)
+    int lo[3], n[3];      // slab origin (local) and extent
+};
+void launch_halo_move(const std::vector<HaloSeg>& segs, bool pack, int elem_bytes, hipStream_t s);
 void launch_box_gather(const BoxCopyArgs& a, hipStream_t s);    // var -> buf
 void launch_box_scatter(const BoxCopyArgs& a, hipStream_t s);   // buf -> var
 void launch_box_fill(const BoxCopyArgs& a, double v, hipStream_t s);

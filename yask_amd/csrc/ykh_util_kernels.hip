@@ -6,6 +6,8 @@
 // src/kernel/lib/yk_var_apis.cpp) and the ref-vs-opt compare (YkVarBase::compare,
 // src/kernel/lib/yk_var.cpp:401-477; tolerance rule src/kernel/lib/realv.hpp:974-994).
 // All are HBM-bound copies: threads run along z (unit stride) so accesses coalesce.
+#include <cstdint>
+
 #include "ykh_runtime.hpp"
 
 namespace ykh {
@@ -229,6 +231,78 @@ __global__ void __launch_bounds__(256) bw_probe_k(const f4* __restrict__ a, cons
     }
     if constexpr (KIND == 2) if (acc.x == 123.456f) d[0] = acc;
 }
+// ------------------------------------------------------------------ halo pack / unpack: all slabs of an exchange in one launch
+constexpr int HALO_SEGS = 40;
+struct HaloSegDev {
+    char* var_base; char* buf;
+    long long sx, sy, sz;            // var strides in ELEMENTS
+    int lo0, lo1, lo2;
+    unsigned n1, n2u;                // rows; units per row (n2 / vec)
+    unsigned vec;                    // elements per unit (1, or 16 / elem_bytes)
+    unsigned long long first;        // first unit of the segment in the launch's unit space
+};
+struct HaloMoveArgs { int nseg; unsigned long long total; int elem_bytes; HaloSegDev seg[HALO_SEGS]; };
+
+template <bool PACK>
+__global__ void __launch_bounds__(256) halo_move_k(const HaloMoveArgs a) {
+    for (unsigned long long u = (unsigned long long)blockIdx.x * 256 + threadIdx.x; u < a.total; u += (unsigned long long)gridDim.x * 256) {
+        int s = 0;
+        for (int k = 1; k < a.nseg; k++) s = (u >= a.seg[k].first) ? k : s;      // (cumulative starts are ascending)
+        const HaloSegDev& g = a.seg[s];
+        const unsigned long long r = u - g.first;
+        const unsigned kv = (unsigned)(r % g.n2u);
+        const unsigned long long rows = r / g.n2u;
+        const unsigned j = (unsigned)(rows % g.n1);
+        const long long i = (long long)(rows / g.n1);
+        const long long ve = (g.lo0 + i) * g.sx + (g.lo1 + (long long)j) * g.sy + (g.lo2 + (long long)kv * g.vec) * g.sz;     // var element
+        char* vp = g.var_base + ve * a.elem_bytes;
+        char* bp = g.buf + r * (unsigned long long)(g.vec * a.elem_bytes);
+        if (g.vec * a.elem_bytes == 16) {
+            if (PACK) *reinterpret_cast<uint4*>(bp) = *reinterpret_cast<const uint4*>(vp);
+            else *reinterpret_cast<uint4*>(vp) = *reinterpret_cast<const uint4*>(bp);
+        } else if (a.elem_bytes == 4) {
+            if (PACK) *reinterpret_cast<unsigned*>(bp) = *reinterpret_cast<const unsigned*>(vp);
+            else *reinterpret_cast<unsigned*>(vp) = *reinterpret_cast<const unsigned*>(bp);
+        } else {
+            if (PACK) *reinterpret_cast<unsigned long long*>(bp) = *reinterpret_cast<const unsigned long long*>(vp);
+            else *reinterpret_cast<unsigned long long*>(vp) = *reinterpret_cast<const unsigned long long*>(bp);
+        }
+    }
+}
+
+void launch_halo_move(const std::vector<HaloSeg>& segs, bool pack, int elem_bytes, hipStream_t st) {
+    if (elem_bytes != 4 && elem_bytes != 8) YKH_THROW("halo pack: element size must be 4 or 8 bytes");
+    const unsigned V = 16u / (unsigned)elem_bytes;
+    size_t k = 0;
+    while (k < segs.size()) {
+        HaloMoveArgs a;
+        a.nseg = 0; a.total = 0; a.elem_bytes = elem_bytes;
+        for (; k < segs.size() && a.nseg < HALO_SEGS; k++) {
+            const HaloSeg& h = segs[k];
+            if (h.n[0] <= 0 || h.n[1] <= 0 || h.n[2] <= 0) continue;
+            HaloSegDev& d = a.seg[a.nseg];
+            d.var_base = (char*)h.var_base; d.buf = (char*)h.buf;
+            d.sx = h.sx; d.sy = h.sy; d.sz = h.sz;
+            d.lo0 = h.lo[0]; d.lo1 = h.lo[1]; d.lo2 = h.lo[2];
+            // 16-byte units where every row of the slab starts and ends on a vector boundary on both sides
+            const bool vec_ok = h.sz == 1 && h.n[2] % (int)V == 0 && (((long long)h.lo[2]) % (long long)V + V) % V == 0 &&
+                                h.sy % V == 0 && h.sx % V == 0 && ((uintptr_t)h.var_base % 16) == 0 && ((uintptr_t)h.buf % 16) == 0;
+            d.vec = vec_ok ? V : 1;
+            d.n1 = (unsigned)h.n[1];
+            d.n2u = (unsigned)h.n[2] / d.vec;
+            d.first = a.total;
+            a.total += (unsigned long long)h.n[0] * d.n1 * d.n2u;
+            a.nseg++;
+        }
+        if (a.nseg == 0 || a.total == 0) continue;
+        const unsigned long long want = (a.total + 255) / 256;
+        const unsigned blocks = (unsigned)std::min<unsigned long long>(want, 16384);       // (grid-strided beyond that)
+        if (pack) hipLaunchKernelGGL(halo_move_k<true>, dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(halo_move_k<false>, dim3(blocks), dim3(256), 0, st, a);
+        YKH_HIP(hipGetLastError());
+    }
+}
+
 // ------------------------------------------------------------------ stream-ordered waits on words in device memory
 // wait_words_kernel: ONE wave; lane i polls word i until it has reached its value (wrap-safe `>=`), then the kernel ends and the
 // stream goes on.  Used (a) by the comm stream to wait for the shell blocks of a planned launch that is still running on the

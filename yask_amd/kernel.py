@@ -562,6 +562,10 @@ class yk_env:
         """Device-to-device transport between the ranks of one host (HIP IPC handles + stream-ordered flags, ykh_ipc.cpp)."""
         self._lib.call_rc("yk_env_init_ipc", self._h, int(rank), int(num_ranks), _b(addr), int(base_port))
 
+    def init_mirror(self, rank, num_ranks):
+        """Timing instrument (see yk_env_init_mirror): this process plays one rank of a decomposed job, its messages come back to it."""
+        self._lib.call_rc("yk_env_init_mirror", self._h, int(rank), int(num_ranks))
+
     def transport_loopback(self, nbytes=1 << 22):
         """Run the installed halo transport once with this rank as its own peer and verify the bytes."""
         self._lib.call_rc("yk_env_transport_loopback", self._h, int(nbytes))
