@@ -236,6 +236,44 @@ def cpu_baseline():
 
 
 # ---------------------------------------------------------------------------------------------- main
+def live_traffic(args, kernel_name):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two short rocprofv3 passes of this very workload, one counter
+    each (FETCH_SIZE, WRITE_SIZE -- never combined with other trace domains), corrected as MI355X_MICROARCH.md prescribes for
+    gfx950 (FETCH_SIZE is in KiB and counts wide coalesced reads at half their size: x 1024 x 2; WRITE_SIZE KiB x 1024).
+    Returns (bytes, source text) or (None, None) when rocprofv3 is not on the box or a pass fails."""
+    import csv
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, None
+    family = kernel_name.split("_")[0]            # starlin / march / ...
+    vals = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-f", "csv", "-d", f"{td}/{ctr}", "--", sys.executable, str(ROOT / "bench.py"),
+                       "--workload", args.workload, "--steps", "4", "--warmup", "1", "--ramp-secs", "0", "--no-cpu-baseline", "--no-probe",
+                       "--traffic", "none", "--opts=-hip_placement_trials 1 " + args.opts]
+                if args.size:
+                    cmd += ["--size", str(args.size)]
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=180)
+                if r.returncode != 0:
+                    return None, None
+                got = []
+                for f in glob.glob(f"{td}/{ctr}/**/*counter_collection.csv", recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if row.get("Counter_Name") == ctr and family in row.get("Kernel_Name", ""):
+                            got.append(float(row["Counter_Value"]))
+                if not got:
+                    return None, None
+                vals[ctr] = sum(got) / len(got)
+        traffic = vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024
+        return traffic, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one counter per pass, 4 steps each) on the '" + family +
+                         "' launches of this workload; FETCH_SIZE KiB x 1024 x 2 (gfx950 counts wide coalesced reads at half size) + WRITE_SIZE KiB x 1024")
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,15 +294,19 @@ def main():
                     help="N>1: halo transport.  ipc: device-to-device copies through HIP IPC handles + stream-ordered flags; rccl: grouped "
                          "ncclSend/ncclRecv; torch: torch.distributed P2P (host-staged with gloo: tests).  auto (default): ipc and rccl each "
                          "run a few steps during warm-up, the faster one is used and both timings are reported")
-    ap.add_argument("--schedule", default="auto", choices=["auto", "planned", "planned30", "planned65", "slabs2", "serial"],
-                    help="N>1: how a step is issued.  planned / planned30 / planned65: the rank box as ONE launch, shell blocks first (done "
-                         "after 45 / 30 / 65 %% of the launch), the halo exchange released from the device when they are done; slabs2: "
-                         "exterior slabs, then the exchange beside the interior cut into 2 launches (round 2); serial: the whole box, "
+    ap.add_argument("--schedule", default="auto", choices=["auto", "planned", "planned35", "slabs", "serial"],
+                    help="N>1: how a step is issued.  planned / planned35: the rank box as ONE launch of equal blocks, shell blocks first (done "
+                         "after 55 / 35 %% of the launch), the halo exchange released from the device when they are done; slabs: "
+                         "exterior slabs, then the exchange beside the interior (round 2); serial: the whole box, "
                          "then the exchange (-no-overlap_comms).  auto (default): every candidate runs a few steps during warm-up, "
                          "the fastest (max over ranks) is used for the timed region and all timings are reported")
     ap.add_argument("--opts", default="", help="extra yask options, e.g. '-hip_variant NAME'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the streaming-bandwidth probe of this box")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "none"],
+                    help="roofline.traffic (HBM bytes per launch): live = two short rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this very "
+                         "workload after the timed region; file = the number recorded in profiles/hbm_traffic.json (labelled as such); "
+                         "auto (default) = live at N=1 when rocprofv3 is on the box, else file")
     # yask options start with '-': hand "--opts '-hip_variant X'" to argparse as "--opts=-hip_variant X"
     argv = sys.argv[1:]
     for i in range(len(argv) - 1):
@@ -390,12 +432,11 @@ def main():
     # ---- N>1: the launch schedule of a step is chosen by measurement (the reference's auto-tuner does the same with its block
     # sizes before the trials, yask_main.cpp:334-335): which of "hide the exchange behind a split interior" and "one full-speed
     # launch, then the exchange" wins depends on link speed vs the cost of cutting the box
-    # "planned*": the rank box as ONE launch, shell blocks first, the exchange released from the device when they are done (round 3;
-    # the shell is cut to be done after 45 / 30 / 65 % of the launch: earlier = more time to hide the exchange in, later = fewer and
-    # longer shell blocks = less prologue overhead); "slabs2": round 2's exterior slabs + interior in two launches
-    SCHEDULES = {"planned": "-overlap_comms -hip_planned_launch -hip_shell_pct 45", "planned30": "-overlap_comms -hip_planned_launch -hip_shell_pct 30",
-                 "planned65": "-overlap_comms -hip_planned_launch -hip_shell_pct 65",
-                 "slabs2": "-overlap_comms -no-hip_planned_launch -hip_overlap_splits 2", "serial": "-no-overlap_comms"}
+    # "planned" / "planned35": the rank box as ONE launch of equal blocks in rounds, shell blocks first, the exchange released from the
+    # device when they are done (round 3; the shell is to be done after 55 / 35 % of the launch: earlier = more rounds = more chunk
+    # prologues); "slabs": round 2's exterior slabs, then the interior; "serial": the whole box, then the exchange
+    SCHEDULES = {"planned": "-overlap_comms -hip_planned_launch -hip_shell_pct 55", "planned35": "-overlap_comms -hip_planned_launch -hip_shell_pct 35",
+                 "slabs": "-overlap_comms -no-hip_planned_launch -hip_overlap_splits 1", "serial": "-no-overlap_comms"}
     schedule, schedule_ms = None, None
     t = 0
     if world > 1:
@@ -469,8 +510,10 @@ def main():
         kern_src = "mean of the per-step HIP events of the timed region (compute stream; a step = the part launches, launch gaps included)"
     achieved = BYTES_PER_POINT * pts_per_gpu / (kern_ms * 1e-3) * 1e-9
     traffic, traffic_src = None, None
+    if world == 1 and rank == 0 and args.traffic in ("auto", "live"):
+        traffic, traffic_src = live_traffic(args, soln.get_kernel_variant(0))
     tf = ROOT / "profiles" / "hbm_traffic.json"
-    if tf.exists() and args.workload == "iso3dfd" and list(local) == [1024, 1024, 1024]:
+    if traffic is None and args.traffic != "none" and tf.exists() and args.workload == "iso3dfd" and list(local) == [1024, 1024, 1024]:
         try:
             tj = json.load(open(tf))
             traffic = tj.get("iso3dfd_1024_bytes_per_launch")

@@ -137,7 +137,7 @@ def test_thin_exterior_slabs_on_the_point_kernel(gpu):
     """Default for y/z decompositions: exterior slabs much thinner than a marching tile are computed by the point
     kernel (different summation order -> compare with the stated tolerance, not bit-exactly)."""
     g, steps = (40, 48, 96), 3
-    two = _two_ranks("iso3dfd", g, steps, "", (1, 1, 2))
+    two = _two_ranks("iso3dfd", g, steps, "-no-hip_planned_launch", (1, 1, 2))       # (the slab schedule: planned launches have no thin slabs)
     ref = O.run_iso3dfd(g, steps)[("p", steps)]
     assert O.rel_linf(two["p"], ref) <= 2e-5
 
@@ -172,7 +172,7 @@ def test_bench_two_ranks_on_one_gpu(gpu):
     assert j["halo"]["bytes_sent_per_step_rank0"] > 0 and j["step_ms"]["n"] == 4
     # the step's launch schedule was picked by timing every candidate during warm-up (max over ranks), and is reported
     tr = j["config"]["schedule_trials_ms_per_step"]
-    assert set(tr) == {"planned", "planned30", "planned65", "slabs2", "serial"} and all(v > 0 for v in tr.values())
+    assert set(tr) == {"planned", "planned35", "slabs", "serial"} and all(v > 0 for v in tr.values())
     assert j["config"]["schedule"] == min(tr, key=tr.get) and j["config"]["overlap_comms"] == (j["config"]["schedule"] != "serial")
     # the default mode cuts ONE global grid over the ranks (strong scaling, north_star's "1024^3 at 1, 2, 4, 8")
     cmd[cmd.index("--config") + 1] = "c2"

@@ -29,13 +29,12 @@ SSG_CASES = [
 CONFIGS = [  # label, options
     ("planned rounds pct55 (default)", "-hip_planned_launch -hip_shell_pct 55 -hip_plan_mode 0"),
     ("planned rounds pct35", "-hip_planned_launch -hip_shell_pct 35 -hip_plan_mode 0"),
-    ("planned pct45 greedy", "-hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 1"),
-    ("planned pct45 uniform", "-hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 2"),
-    ("planned pct30 greedy", "-hip_planned_launch -hip_shell_pct 30 -hip_plan_mode 1"),
-    ("planned pct65 greedy", "-hip_planned_launch -hip_shell_pct 65 -hip_plan_mode 1"),
-    ("planned pct80 greedy", "-hip_planned_launch -hip_shell_pct 80 -hip_plan_mode 1"),
+    ("first planner: thin x slabs + per-CU budgets", "-hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 1"),
+    ("first planner: uniform interior chunks", "-hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 2"),
     ("slabs, interior in 2 launches (round 2 default)", "-no-hip_planned_launch -hip_overlap_splits 2"),
     ("slabs, interior in 1 launch", "-no-hip_planned_launch -hip_overlap_splits 1"),
+    # compute side of the multi-rank wave-front tiling: one step's share of a 2-step group on extended, shrinking boxes
+    ("wave-front tiling across ranks, -Mbt 2 (per step)", "-Mbt 2 -hip_wf_ext_always"),
 ]
 
 
@@ -52,7 +51,7 @@ def main():
     cases = SSG_CASES if args.stencil == "ssg" else CASES
     configs = CONFIGS
     if args.quick:
-        cases, configs = cases[:2], [CONFIGS[0], CONFIGS[1], CONFIGS[6]]
+        cases, configs = cases[:2], [CONFIGS[0], CONFIGS[5], CONFIGS[6]]
     out = []
     for name, size, lo, hi in cases:
         for label, opts in configs:

@@ -1,0 +1,102 @@
+#!/usr/bin/env python
+"""Like-for-like divergence table for ssg: the same grid, the same initial data, the same step
+counts on every side, mismatches counted with the reference's own rule (`within_tolerance`, eps = 1e-3, realv.hpp:974-994).
+
+The reference's `-validate` and ours compare an optimised path with a scalar one; with ssg's test coefficients the scheme amplifies
+rounding differences, so ANY two roundings of it drift apart.  The question the round-2 verdict left open: does the reciprocal
+division of the default ssg shapes (`-hip_fast_div`, a * v_rcp_f32(b)) drift EARLIER than what the reference ships itself?
+Columns (all 9 fields, 64^3, logical-index hash init, so storage layout plays no part):
+  ref avx512 vs ref intel64        two roundings of the unmodified reference (vector folding changes the summation order)
+  ref rcp14  vs ref avx512         the reference's own `use_rcp=1` build (A * rcp14(B), 2^-14) against its exact-division build
+  hip exact  vs ref avx512         -no-hip_fast_div: correctly rounded divisions
+  hip fast   vs ref avx512         the reciprocal-division shapes (<= 1.5 ulp)
+  hip fast   vs hip exact
+  hip exact / hip fast vs hip point kernel    what our harness's -validate compares
+Needs oracle/_ref (reference builds: `make -C oracle ref-kernel STENCIL=ssg TAG=ssg ARCH=avx512|intel64` and
+`TAG=ssg_rcp14 EXTRA_DEFS=-DUSE_RCP14`) and a GPU.  --ref-only: the reference columns alone (no GPU)."""
+import argparse
+import json
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+from oracle import oracle as O  # noqa: E402
+
+REF = ROOT / "oracle" / "_ref" / "bin"
+
+
+def run_ref(tag, arch, n, steps):
+    exe = REF / f"ref_driver.{tag}.{arch}.exe"
+    if not exe.exists():
+        return None
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        cmd = [str(exe), "-g", str(n), str(n), str(n), "-steps", str(steps), "-out", f"{td}/o"]
+        for v, (off, sc) in O.DEFAULT_INIT["ssg"].items():
+            cmd += ["-init", f"{v}:{off}:{sc}"]
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        man = json.load(open(f"{td}/o.json"))
+        out = {}
+        for v in man["vars"]:
+            if v["has_step"] and v["step"] == steps:
+                out[v["name"]] = np.fromfile(f"{td}/{v['file']}", dtype=np.float32).reshape(v["shape"]).copy()
+        return out
+
+
+def run_hip(n, steps, opts):
+    from yask_amd import yk_factory
+    from yask_amd.kernel import yk_env
+    yk_env.disable_debug_output()
+    fac = yk_factory("ssg")
+    s = fac.new_solution(fac.new_env())
+    s.set_overall_domain_size_vec([n, n, n])
+    assert s.apply_command_line_options("-no-auto_tune " + opts) == ""
+    s.prepare_solution()
+    for v in s.get_vars():
+        v.set_elements_hash(*O.DEFAULT_INIT["ssg"][v.get_name()], hash_id=O.VAR_IDS["ssg"][v.get_name()])
+    s.run_solution(0, steps - 1)
+    out = {f: s.get_var(f).get_elements_in_slice([steps, 0, 0, 0], [steps, n - 1, n - 1, n - 1])[0].copy() for f in O.SSG_FIELDS}
+    kern = [s.get_kernel_variant(p) for p in range(s.get_num_parts())]
+    s.end_solution()
+    return out, kern
+
+
+def mismatches(a, b):
+    if a is None or b is None:
+        return None
+    return int(sum((~O.within_tolerance(a[f], b[f])).sum() for f in O.SSG_FIELDS))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--steps", type=int, nargs="+", default=[4, 10, 20, 40])
+    ap.add_argument("--ref-only", action="store_true")
+    args = ap.parse_args()
+    arch = "avx512" if "avx512f" in open("/proc/cpuinfo").read() else "avx2"
+    rows = []
+    for st in args.steps:
+        r512 = run_ref("ssg", arch, args.size, st)
+        r64 = run_ref("ssg", "intel64", args.size, st)
+        rrcp = run_ref("ssg_rcp14", arch, args.size, st)
+        row = {"steps": st, "points": 9 * args.size ** 3, "ref_vec_vs_ref_scalar": mismatches(r512, r64), "ref_rcp14_vs_ref_exact": mismatches(rrcp, r512)}
+        if not args.ref_only:
+            exact, k_exact = run_hip(args.size, st, "-no-hip_fast_div")
+            fast, k_fast = run_hip(args.size, st, "-hip_fast_div")
+            point, _ = run_hip(args.size, st, "-force_scalar")
+            row.update({"hip_exact_vs_ref": mismatches(exact, r512), "hip_fast_vs_ref": mismatches(fast, r512), "hip_fast_vs_hip_exact": mismatches(fast, exact),
+                        "hip_exact_vs_hip_point": mismatches(exact, point), "hip_fast_vs_hip_point": mismatches(fast, point),
+                        "kernels_exact": k_exact, "kernels_fast": k_fast})
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+    od = ROOT / "gpurun_out"
+    od.mkdir(exist_ok=True)
+    json.dump(rows, open(od / ("validate_table_ref.json" if args.ref_only else "validate_table.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
