@@ -85,8 +85,10 @@ def main():
         rrcp = run_ref("ssg_rcp14", arch, args.size, st)
         row = {"steps": st, "points": 9 * args.size ** 3, "ref_vec_vs_ref_scalar": mismatches(r512, r64), "ref_rcp14_vs_ref_exact": mismatches(rrcp, r512)}
         if not args.ref_only:
-            exact, k_exact = run_hip(args.size, st, "-no-hip_fast_div")
-            fast, k_fast = run_hip(args.size, st, "-hip_fast_div")
+            # (the shapes are named: on a grid this small prepare_solution() would otherwise pick by tile fill, and both runs would
+            #  use the same shape; these two exist for both stages and differ in the divisions only)
+            exact, k_exact = run_hip(args.size, st, "-hip_variant march_v4_z128_y16_nt_hr_w2")
+            fast, k_fast = run_hip(args.size, st, "-hip_variant march_v4_z128_y16_nt_hr_fd_w2")
             point, _ = run_hip(args.size, st, "-force_scalar")
             row.update({"hip_exact_vs_ref": mismatches(exact, r512), "hip_fast_vs_ref": mismatches(fast, r512), "hip_fast_vs_hip_exact": mismatches(fast, exact),
                         "hip_exact_vs_hip_point": mismatches(exact, point), "hip_fast_vs_hip_point": mismatches(fast, point),
