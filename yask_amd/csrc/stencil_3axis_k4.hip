@@ -12,5 +12,12 @@ void s3axis_variants_k4(PartImpl& p) {
     p.variants.push_back(starlin_variant<part_1, 2, 64, 16, 2, ROT_MOVE, 1, 4, 4>());     // tile 128x32 on 1024 threads: 120 VGPRs, 4 waves per SIMD
     p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 2, ROT_MOVE, 1, 4, 4>());      // tile 128x16, 126 VGPRs: two workgroups per CU
     p.variants.push_back(starlin_variant<part_1, 2, 32, 16, 2, ROT_TRIP2, 9, 2, 4>());
+    // round 3 (fp64 is latency-bound at 2 waves per SIMD): more waves instead of more rows per thread --
+    // one row per thread on 1024 threads, tile 128 x 16 (94-102 VGPRs: 4-5 waves per SIMD), with queue renaming and planes two ahead
+    p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_TRIP2, 1, 2, 2>());     // the large-grid shape, LDS batches of 2 (246 VGPRs)
+    p.variants.push_back(starlin_variant<part_1, 2, 64, 16, 1, ROT_TRIP2, 9, 4, 4>());
+    p.variants.push_back(starlin_variant<part_1, 2, 64, 16, 1, ROT_TRIP2, 1, 4, 4>());
+    p.variants.push_back(starlin_variant<part_1, 2, 32, 32, 1, ROT_TRIP2, 9, 4, 4>());    // tile 64 x 32 on 1024 threads
+    p.variants.push_back(starlin_variant<part_1, 2, 64, 16, 1, ROT_TRIP2, 25, 4, 4>());   // + operands two planes ahead
 }
 }  // namespace ykh
