@@ -19,5 +19,7 @@ void s3axis_variants_k4(PartImpl& p) {
     p.variants.push_back(starlin_variant<part_1, 2, 64, 16, 1, ROT_TRIP2, 1, 4, 4>());
     p.variants.push_back(starlin_variant<part_1, 2, 32, 32, 1, ROT_TRIP2, 9, 4, 4>());    // tile 64 x 32 on 1024 threads
     p.variants.push_back(starlin_variant<part_1, 2, 64, 16, 1, ROT_TRIP2, 25, 4, 4>());   // + operands two planes ahead
+    p.variants.push_back(starlin_variant<part_1, 2, 32, 16, 2, ROT_UNROLL, 1 | 64, 2, 4>());   // the default shape + cheap tail planes (_tl)
+    p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_MOVE, 1 | 64, 2, 4>());      // the large-grid shape + cheap tail planes
 }
 }  // namespace ykh

@@ -12,7 +12,11 @@ void iso3dfd_variants_k4(PartImpl& p) {
     p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 17, 2, 2, 0>());   // + operands two planes ahead
     p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 9, 2, 2, 0>());    // + star planes two planes ahead
     p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_TRIP, 9, 2, 2, 0>());    // + queue renaming within the 2-plane trip
-    p.variants.push_back(starlin_variant_planned<part_1, 4, 32, 16, 2, ROT_TRIP2, 9, 2, 2>());     // (+ twin for planned launches)   // + 4-plane trips
+    p.variants.push_back(starlin_variant_planned<part_1, 4, 32, 16, 2, ROT_TRIP2, 9, 2, 2>());     // (+ twin for planned launches)
+    // + cheap tail planes (_tl): the main loop is the plain shape's, the block's last XH planes take a path without halo / slab / barrier
+    p.variants.push_back(starlin_variant_planned<part_1, 4, 32, 16, 2, ROT_TRIP2, 9 | 64, 2, 2>());      // 256 VGPRs, no scratch
+    p.variants.push_back(starlin_variant_planned<part_1, 4, 32, 16, 2, ROT_TRIP, 9 | 64, 2, 2>());
+    p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 9 | 64, 2, 2>());   // + 4-plane trips
     p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 29, 2, 2, 0>());   // + both, halos at the end
     p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 13, 2, 2, 0>());   // planes two ahead, halos at the end
     p.variants.push_back(starlin_variant<part_1, 4, 64, 8, 2, ROT_MOVE, 9, 2, 2, 0>());     // 256x16 tile, planes two ahead

@@ -253,6 +253,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
     constexpr int PD = ((NTH >> 5) & 1) ? 3 : (((NTH >> 3) & 1) ? 2 : 1);      // prefetch depth in planes (bit 5: three)
     constexpr int CD = ((NTH >> 4) & 1) ? 2 : 1;      // prefetch depth of the centre-only operands
     constexpr int TRIP = PD * CD / ce_gcd(PD, CD);    // planes per loop trip (the register sets rotate)
+    constexpr bool TAILOPT = ((NTH >> 6) & 1) != 0;   // bit 6: cheap tail planes (see plane())
     static_assert(CD == 1 || XH > 0, "operand prefetch depth 2 needs a future x range");
     static_assert(!C::R.mixed, "linear form has a mixed-offset term");
     static_assert(NG <= MAX_GROUPS, "too many access groups");
@@ -378,8 +379,9 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
     // One arriving plane. PH renames the queue slots when the loop is unrolled PERIOD times.
     // `set_tag`: which prefetch register set holds the arriving plane (PD == 2: the plane's parity).
     // `trip_tag`: position of the plane within a loop trip; selects the alternating register sets.
-    auto plane = [&](int xin, auto ph_tag, auto trip_tag) {
+    auto plane = [&](int xin, auto ph_tag, auto trip_tag, auto tail_tag) {
         constexpr int PH = decltype(ph_tag)::value;
+        constexpr bool ALLOW_TAIL = decltype(tail_tag)::value;      // only the epilogue of a _tl shape compiles the tail path
         constexpr int S = decltype(trip_tag)::value % PD;
         constexpr int CS = decltype(trip_tag)::value % CD;
         typedef std::integral_constant<int, S> set_t;
@@ -388,121 +390,138 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
         constexpr int qn = rot<NP>(PH, NP - 1), an = rot<NA>(PH, NA - 1);
         constexpr int qo = rot<NP>(PH, NP - 1 - XH), ao = rot<NA>(PH, 0);
         T* sb;
-        if constexpr (ROT == ROT_UNROLL) sb = slab + (PH % C::NS) * (C::LROWS * LP);
+        if constexpr (ALLOW_TAIL) sb = slab + ((xin - xs) % C::NS) * (C::LROWS * LP);        // (epilogue: continues the main loop's ring)
+        else if constexpr (ROT == ROT_UNROLL) sb = slab + (PH % C::NS) * (C::LROWS * LP);
         else if constexpr (ROT == ROT_TRIP || ROT == ROT_TRIP2) sb = slab + (decltype(trip_tag)::value & 1) * (C::LROWS * LP);   // (even trips)
         else sb = slab + ((xin - xs) & 1) * (C::LROWS * LP);
         const int xo = xin - XH;
-        static_for<RY>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            pq[qn][j] = nxt[S][j];
-            stv<V>(sb + (YL + ly * RY + j) * LP + (ZLV + lz) * VZ, nxt[S][j]);
-        });
-        static_for<NHT>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            if constexpr ((k + 1) * NT <= C::NH) stv<V>(sb + hlds[k], hreg[S][k]);      // every thread has one
-            else if (hlds[k] >= 0) stv<V>(sb + hlds[k], hreg[S][k]);
-        });
-        // prefetch the next arriving plane (registers of nxt/hreg are free again)
-        load_interior(xin + PD, set_tag);
-        if constexpr (HALO_LATE == 0) load_halo(xin + PD, set_tag);
-        __syncthreads();
-
-        const T* colp = sb + (ZLV + lz) * VZ;
-        const T* row0 = colp + (YL + ly * RY) * LP;      // the thread's first row in the slab
-        // ---- new partial sums for output plane xin, all RY rows of the thread together.
-        // Centre and past x come from registers ...
+        // TAILOPT (NTH bit 6, "_tl"): the last XH planes of a block (xin >= xe) arrive only to complete the outputs that are still
+        // waiting for their +x neighbours: they need the plane's own points -- no halo, no slab, no barrier, no y/z sums (the
+        // partial sum of output plane xin itself belongs to the next block).  A block then pays ~1 plane-equivalent for its tail
+        // instead of XH: the prologue overhead that makes short x-chunks expensive (512^3: 4 chunks of 128 + 8; planned launches
+        // of a decomposed rank: 8 chunks of 64 + 8).  Uniform branch; the arithmetic of every stored point is unchanged.
+        const bool tail = ALLOW_TAIL && xin >= xe;
         V c[RY], sum[RY];
-        static_for<RY>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            const T c000 = lin_coef_of<P, 0, 0, 0>(cs);
-            c[j] = pq[qn][j];
-            sum[j] = c[j] * c000;
-            static_for<XL>([&](auto kc) {
-                constexpr int k = decltype(kc)::value + 1;
-                const T ck = lin_coef_of<P, -k, 0, 0>(cs);
-                constexpr int qi = rot<NP>(PH, NP - 1 - k);
-                sum[j] += pq[qi][j] * ck;
+        if (!tail) {
+            static_for<RY>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                pq[qn][j] = nxt[S][j];
+                stv<V>(sb + (YL + ly * RY + j) * LP + (ZLV + lz) * VZ, nxt[S][j]);
             });
-        });
-        // ... the thread's own rows are y-neighbours of each other (registers) ...
-        static_for<RY>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            static_for<RY>([&](auto j2c) {
-                constexpr int dy = decltype(j2c)::value - j;
-                if constexpr (dy != 0 && dy >= -YL && dy <= C::YH) {
-                    if constexpr (lin_coef<P>(0, dy, 0) != 0.0) {
-                        const T ck = lin_coef_of<P, 0, dy, 0>(cs);
-                        sum[j] += c[decltype(j2c)::value] * ck;
+            static_for<NHT>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr ((k + 1) * NT <= C::NH) stv<V>(sb + hlds[k], hreg[S][k]);      // every thread has one
+                else if (hlds[k] >= 0) stv<V>(sb + hlds[k], hreg[S][k]);
+            });
+            // prefetch the next arriving plane (registers of nxt/hreg are free again)
+            load_interior(xin + PD, set_tag);
+            if constexpr (HALO_LATE == 0) { if (!ALLOW_TAIL || xin + PD < xe) load_halo(xin + PD, set_tag); }      // (tail planes use no halo)
+            __syncthreads();
+
+            const T* colp = sb + (ZLV + lz) * VZ;
+            const T* row0 = colp + (YL + ly * RY) * LP;      // the thread's first row in the slab
+            // ---- new partial sums for output plane xin, all RY rows of the thread together.
+            // Centre and past x come from registers ...
+            static_for<RY>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const T c000 = lin_coef_of<P, 0, 0, 0>(cs);
+                c[j] = pq[qn][j];
+                sum[j] = c[j] * c000;
+                static_for<XL>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value + 1;
+                    const T ck = lin_coef_of<P, -k, 0, 0>(cs);
+                    constexpr int qi = rot<NP>(PH, NP - 1 - k);
+                    sum[j] += pq[qi][j] * ck;
+                });
+            });
+            // ... the thread's own rows are y-neighbours of each other (registers) ...
+            static_for<RY>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                static_for<RY>([&](auto j2c) {
+                    constexpr int dy = decltype(j2c)::value - j;
+                    if constexpr (dy != 0 && dy >= -YL && dy <= C::YH) {
+                        if constexpr (lin_coef<P>(0, dy, 0) != 0.0) {
+                            const T ck = lin_coef_of<P, 0, dy, 0>(cs);
+                            sum[j] += c[decltype(j2c)::value] * ck;
+                        }
                     }
+                });
+            });
+            // ... the other y-neighbours come from ONE window of slab rows shared by the RY rows (YL+YH reads
+            // instead of RY*(YL+YH)); every value read feeds the sums of all rows it is a neighbour of, which
+            // also gives RY independent FMA chains.  Reads go in batches of CH, double-buffered: while batch b is
+            // summed, batch b+1 is in flight.  The empty asm pins the partial sums (and, through its memory
+            // clobber, the later reads) in program order; unconstrained, hipcc issues all reads first and needs
+            // VZ*(NYW+NW) more VGPRs.
+            {
+                constexpr int NYW = C::NYW;
+                constexpr int NB = (NYW + CH - 1) / CH;
+                V t[NB > 0 ? NB : 1][CH];
+                auto issue = [&](auto bc) {
+                    constexpr int b = decltype(bc)::value;
+                    static_for<CH>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value, r = b * CH + i;
+                        if constexpr (r < NYW) {
+                            constexpr int w = C::yw_off(r);
+                            t[b][i] = ldv<V>(row0 + w * LP);
+                        }
+                    });
+                };
+                if constexpr (NB > 0) issue(std::integral_constant<int, 0>{});
+                static_for<NB>([&](auto bc) {
+                    constexpr int b = decltype(bc)::value;
+                    if constexpr (b + 1 < NB) issue(std::integral_constant<int, b + 1>{});
+                    static_for<CH>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value, r = b * CH + i;
+                        if constexpr (r < NYW) {
+                            constexpr int w = C::yw_off(r);
+                            static_for<RY>([&](auto jc) {
+                                constexpr int j = decltype(jc)::value;
+                                constexpr int dy = w - j;
+                                if constexpr (dy >= -YL && dy <= C::YH) {
+                                    if constexpr (lin_coef<P>(0, dy, 0) != 0.0) {
+                                        const T ck = lin_coef_of<P, 0, dy, 0>(cs);
+                                        sum[j] += t[b][i] * ck;
+                                    }
+                                }
+                            });
+                        }
+                    });
+                    static_for<RY>([&](auto jc) { pin_reg(sum[decltype(jc)::value]); });
+                });
+            }
+            static_for<RY>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                // ... z neighbours from a window of the row itself
+                constexpr int NZW = (C::ZL + C::ZH > 0) ? C::NW - 1 : 0;       // window reads (own vector comes from c)
+                if constexpr (NZW > 0) {
+                    const T* rowc = row0 + j * LP;
+                    V zw[C::NW];
+                    zw[ZLV] = c[j];
+                    static_for<C::NW>([&](auto wc) {
+                        constexpr int w = decltype(wc)::value;
+                        if constexpr (w != ZLV) zw[w] = ldv<V>(rowc + (w - ZLV) * VZ);
+                    });
+                    static_for<C::ZL + C::ZH + 1>([&](auto dc) {
+                        constexpr int dz = decltype(dc)::value - C::ZL;
+                        if constexpr (dz != 0 && lin_coef<P>(0, 0, dz) != 0.0) {
+                            constexpr int e = ZLV * VZ + dz;
+                            const T ck = lin_coef_of<P, 0, 0, dz>(cs);
+                            sum[j] += zshiftn<T, VZ, e % VZ>(zw[e / VZ], zw[(e / VZ + 1) < C::NW ? (e / VZ + 1) : e / VZ]) * ck;
+                        }
+                    });
+                    pin_reg(sum[j]);
                 }
             });
-        });
-        // ... the other y-neighbours come from ONE window of slab rows shared by the RY rows (YL+YH reads
-        // instead of RY*(YL+YH)); every value read feeds the sums of all rows it is a neighbour of, which
-        // also gives RY independent FMA chains.  Reads go in batches of CH, double-buffered: while batch b is
-        // summed, batch b+1 is in flight.  The empty asm pins the partial sums (and, through its memory
-        // clobber, the later reads) in program order; unconstrained, hipcc issues all reads first and needs
-        // VZ*(NYW+NW) more VGPRs.
-        {
-            constexpr int NYW = C::NYW;
-            constexpr int NB = (NYW + CH - 1) / CH;
-            V t[NB > 0 ? NB : 1][CH];
-            auto issue = [&](auto bc) {
-                constexpr int b = decltype(bc)::value;
-                static_for<CH>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value, r = b * CH + i;
-                    if constexpr (r < NYW) {
-                        constexpr int w = C::yw_off(r);
-                        t[b][i] = ldv<V>(row0 + w * LP);
-                    }
-                });
-            };
-            if constexpr (NB > 0) issue(std::integral_constant<int, 0>{});
-            static_for<NB>([&](auto bc) {
-                constexpr int b = decltype(bc)::value;
-                if constexpr (b + 1 < NB) issue(std::integral_constant<int, b + 1>{});
-                static_for<CH>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value, r = b * CH + i;
-                    if constexpr (r < NYW) {
-                        constexpr int w = C::yw_off(r);
-                        static_for<RY>([&](auto jc) {
-                            constexpr int j = decltype(jc)::value;
-                            constexpr int dy = w - j;
-                            if constexpr (dy >= -YL && dy <= C::YH) {
-                                if constexpr (lin_coef<P>(0, dy, 0) != 0.0) {
-                                    const T ck = lin_coef_of<P, 0, dy, 0>(cs);
-                                    sum[j] += t[b][i] * ck;
-                                }
-                            }
-                        });
-                    }
-                });
-                static_for<RY>([&](auto jc) { pin_reg(sum[decltype(jc)::value]); });
+        } else {
+            static_for<RY>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                pq[qn][j] = nxt[S][j];
+                c[j] = pq[qn][j];
+                sum[j] = V(0);
             });
+            if (xin + PD < xlast) load_interior(xin + PD, set_tag);
         }
-        static_for<RY>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            // ... z neighbours from a window of the row itself
-            constexpr int NZW = (C::ZL + C::ZH > 0) ? C::NW - 1 : 0;       // window reads (own vector comes from c)
-            if constexpr (NZW > 0) {
-                const T* rowc = row0 + j * LP;
-                V zw[C::NW];
-                zw[ZLV] = c[j];
-                static_for<C::NW>([&](auto wc) {
-                    constexpr int w = decltype(wc)::value;
-                    if constexpr (w != ZLV) zw[w] = ldv<V>(rowc + (w - ZLV) * VZ);
-                });
-                static_for<C::ZL + C::ZH + 1>([&](auto dc) {
-                    constexpr int dz = decltype(dc)::value - C::ZL;
-                    if constexpr (dz != 0 && lin_coef<P>(0, 0, dz) != 0.0) {
-                        constexpr int e = ZLV * VZ + dz;
-                        const T ck = lin_coef_of<P, 0, 0, dz>(cs);
-                        sum[j] += zshiftn<T, VZ, e % VZ>(zw[e / VZ], zw[(e / VZ + 1) < C::NW ? (e / VZ + 1) : e / VZ]) * ck;
-                    }
-                });
-                pin_reg(sum[j]);
-            }
-        });
         static_for<RY>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             const V s = sum[j];
@@ -548,9 +567,9 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
                     }
                 });
             }
-            if constexpr (HALO_LATE == 1 && j == 0) load_halo(xin + PD, set_tag);
+            if constexpr (HALO_LATE == 1 && j == 0) { if (!tail) load_halo(xin + PD, set_tag); }
         });
-        if constexpr (HALO_LATE == 2) load_halo(xin + PD, set_tag);
+        if constexpr (HALO_LATE == 2) { if (!tail) load_halo(xin + PD, set_tag); }
         // operands of the next output plane: a whole plane of work hides their latency
         if (xo + CD >= xs && xo + CD < xe) load_centres((idx_t)(xo + CD) * a.sx + org, cset_t{});
     };
@@ -577,22 +596,43 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
         static_for<NA>([&](auto ic) { constexpr int i = decltype(ic)::value; static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; acc[i][j] = ta[rot<NA>(K, i)][j]; }); });
     };
     typedef std::integral_constant<int, 0> I0;
-    if constexpr (ROT == ROT_MOVE) {
+    typedef std::false_type NoTail;
+    if constexpr (TAILOPT) {
+        // _tl shapes: the main loop runs whole trips of full planes only (its code is exactly the plain shape's); what is left of
+        // the block -- fewer than a trip of full planes and the XH tail planes -- goes plane by plane with moved queues, and the
+        // tail planes take the cheap path (plane(): no halo, no slab, no barrier, no y/z sums).
+        int x = xs;
+        if constexpr (ROT == ROT_TRIP || ROT == ROT_TRIP2) {
+            constexpr int K = (ROT == ROT_TRIP2 ? 2 : 1) * (TRIP % 2 == 0 ? TRIP : 2 * TRIP);
+            for (; x + K <= xe; x += K) {
+                static_for<K>([&](auto sc) { plane(x + decltype(sc)::value, sc, sc, NoTail{}); });
+                rotate_by(std::integral_constant<int, K>{});
+            }
+        } else if constexpr (ROT == ROT_UNROLL) {
+            static_assert(C::UNR % TRIP == 0, "the unroll count must be a multiple of the prefetch trip");
+            for (; x + C::UNR <= xe; x += C::UNR)
+                static_for<C::UNR>([&](auto phc) { plane(x + decltype(phc)::value, phc, phc, NoTail{}); });
+        }
+        // (the main loop ran whole trips, so the queues are in canonical order, the prefetch sets and the slab ring continue
+        //  from position 0; ROT_MOVE shapes run everything here)
+        for (; x < xlast; x += TRIP)
+            static_for<TRIP>([&](auto sc) { plane(x + decltype(sc)::value, I0{}, sc, std::true_type{}); rotate(); });
+    } else if constexpr (ROT == ROT_MOVE) {
         // PD planes per trip (the prefetch sets alternate); a trip may run past xlast-1: loads are clamped
         // to the allocation and stores are predicated on xo < xe.
         for (int x = xs; x < xlast; x += TRIP)
-            static_for<TRIP>([&](auto sc) { plane(x + decltype(sc)::value, I0{}, sc); rotate(); });
+            static_for<TRIP>([&](auto sc) { plane(x + decltype(sc)::value, I0{}, sc, NoTail{}); rotate(); });
     } else if constexpr (ROT == ROT_TRIP || ROT == ROT_TRIP2) {
         constexpr int K = (ROT == ROT_TRIP2 ? 2 : 1) * (TRIP % 2 == 0 ? TRIP : 2 * TRIP);     // even: the two slabs alternate
         for (int x = xs; x < xlast; x += K) {
-            static_for<K>([&](auto sc) { plane(x + decltype(sc)::value, sc, sc); });
+            static_for<K>([&](auto sc) { plane(x + decltype(sc)::value, sc, sc, NoTail{}); });
             rotate_by(std::integral_constant<int, K>{});
         }
     } else {
         // UNR planes per trip (queue rotation by renaming); the last trip may run past xlast-1.
         static_assert(C::UNR % TRIP == 0, "the unroll count must be a multiple of the prefetch trip");
         for (int x = xs; x < xlast; x += C::UNR)
-            static_for<C::UNR>([&](auto phc) { plane(x + decltype(phc)::value, phc, phc); });
+            static_for<C::UNR>([&](auto phc) { plane(x + decltype(phc)::value, phc, phc, NoTail{}); });
     }
     if constexpr (DESC) block_done(a, bb.flags);
 }
