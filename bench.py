@@ -16,9 +16,12 @@ N>1 is launched by the driver as `python -m torch.distributed.run ... bench.py -
   --config c4          : BASELINE.json configs[3]: 1024x1024x512 points per GPU on the compact rank grid, i.e.
                          2048x2048x1024 on 8 GPUs (2x2x2);
   --config weak        : one 1024^3 block per GPU in x-slabs (round 1's mode).
-Halos travel as RCCL send/recv on a side stream; whether the exchange is hidden behind an interior cut into 1 / 2 / 4 launches
-or follows one full-speed launch of the whole box is decided by timing the four schedules during warm-up (--schedule auto, the
-timings are in the JSON line); a failing RCCL set-up is an error, not a fallback.  Rank 0 prints ONE JSON line.
+Halos travel either as device-to-device copies into the neighbour's buffers through HIP IPC handles (no CU, no host in the
+loop) or as RCCL send/recv on a side stream: both are set up and timed during warm-up and the faster one is kept (--transport
+auto; config.transport / transport_trials_ms).  The rank box is ONE planned launch (shell blocks first, the exchange released from
+the device) or round 2's slab / serial schedules: the four are timed during warm-up as well (--schedule auto, timings in the JSON
+line); a failing transport set-up is an error, not a fallback.  Rank 0 prints ONE JSON line.  roofline.traffic is measured live
+(two rocprofv3 --pmc passes of the same workload after the timed region, N=1 only; --traffic off skips them).
 prepare_solution() draws several sets of var allocations, times a step on each and keeps the fastest (config.var_placement).
 
 Measurement hygiene (VERDICT r01 "weak" #2): after the W warm-up steps the job keeps stepping, untimed, until
