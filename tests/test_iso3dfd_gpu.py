@@ -60,6 +60,31 @@ def test_every_kernel_variant_matches_oracle(gpu):
         soln.end_solution()
 
 
+def test_marching_shapes_agree_bit_for_bit_whatever_the_chunking(gpu):
+    """Every starlin shape with the same rows-per-thread count sums in the same order (x past, own rows, slab rows, z, x future):
+    tile size, queue rotation (_m / _t / _t2 / _u), prefetch depth, cheap tails (_tl) and the x-chunk length -- odd ones included --
+    must not move the last bit.  (They did until the sums were explicit FMAs: ykh_device.hpp fmacc.)"""
+    import re
+    size, steps = (150, 45, 200), 3
+    groups = {}
+    for name in variants():
+        m = re.match(r"starlin_v\d+_z\d+_y\d+_r(\d+)_", name)
+        if m:
+            groups.setdefault(m.group(1), []).append(name)
+    assert groups
+    for ry, names in sorted(groups.items()):
+        first = None
+        for k, name in enumerate(names):
+            _, _, soln = make(size, f"-hip_variant {name} -hip_xchunk {(37, 64, 0, 51)[k % 4]}")
+            soln.run_solution(0, steps - 1)
+            got = domain_slice(soln, soln.get_var("p"), steps).copy()
+            soln.end_solution()
+            if first is None:
+                first = got
+            else:
+                assert np.array_equal(first, got), (ry, names[0], name, int((first != got).sum()))
+
+
 @pytest.mark.parametrize("xchunk", [1, 5, 16, 1000])
 def test_x_chunking_is_transparent(gpu, xchunk):
     size, steps = (33, 20, 64), 2

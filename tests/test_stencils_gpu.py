@@ -63,6 +63,29 @@ def test_axis3_every_variant_matches_oracle(gpu):
         soln.end_solution()
 
 
+def test_axis3_marching_shapes_agree_bit_for_bit_whatever_the_chunking(gpu):
+    """fp64 twin of test_iso3dfd_gpu.test_marching_shapes_agree_bit_for_bit_whatever_the_chunking."""
+    import re
+    size, steps = (150, 45, 120), 3
+    groups = {}
+    for name in variant_names("3axis"):
+        m = re.match(r"starlin_v\d+_z\d+_y\d+_r(\d+)_", name)
+        if m:
+            groups.setdefault(m.group(1), []).append(name)
+    assert groups
+    for ry, names in sorted(groups.items()):
+        first = None
+        for k, name in enumerate(names):
+            soln = make("3axis", size, f"-hip_variant {name} -hip_xchunk {(37, 64, 0, 51)[k % 4]}")
+            soln.run_solution(0, steps - 1)
+            got = domain_slice(soln, soln.get_var("A"), steps).copy()
+            soln.end_solution()
+            if first is None:
+                first = got
+            else:
+                assert np.array_equal(first, got), (ry, names[0], name, int((first != got).sum()))
+
+
 @pytest.mark.parametrize("name", [n for n in INDEX if INDEX[n]["stencil"] == "3axis" and "lattice_stride" not in INDEX[n]])
 def test_axis3_matches_reference_golden(gpu, name):
     meta = INDEX[name]

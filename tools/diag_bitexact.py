@@ -36,9 +36,11 @@ def run_one(opts):
     return out, kern
 
 
-def worker(rank, world, port, q, nr, opts, steps):
-    global STEPS
+def worker(rank, world, port, q, nr, opts, steps, planes=None):
+    global STEPS, PLANES
     STEPS = steps
+    if planes is not None:
+        PLANES = planes
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), YASK_HIP_TRANSPORT="tcp")
     from yask_amd import yk_factory
     fac = yk_factory("iso3dfd")

@@ -27,7 +27,9 @@ const SolnImpl& ykh_solution_impl() {
         iso3dfd_variants_k4(p);
         iso3dfd_variants_k5(p);
         iso3dfd_variants_k6(p);
-        p.set_default("starlin_v4_z128_y32_r2_t2_nt_pd2_w2_c2");     // same box A/B (gpurun_out/r03c): 358.3 vs 349.0 Gpoints/s for _m
+        // same box A/B (gpurun_out/r03c): _t2 358.3 vs 349.0 Gpoints/s for _m; round 3 (gpurun_out/r3j, bit-identical shapes):
+        // + cheap tail planes 1024^3 2.911 vs 2.979 ms, 512^3 0.418 vs 0.428 ms, 1024x1024x512 1.535 vs 1.536 ms
+        p.set_default("starlin_v4_z128_y32_r2_t2_nt_pd2_tl_w2_c2");
         s.parts.push_back(p);
         return s;
     }();

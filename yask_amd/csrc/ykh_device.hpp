@@ -34,6 +34,15 @@
 
 namespace ykh {
 
+// s + v * ck as ONE fused multiply-add, spelled out.  The partial sums of the marching kernels start as a product
+// (`sum = centre * c0`) and continue `sum += neighbour * ck`: under -ffp-contract=fast the first of those adds is mul + mul, and
+// the compiler may fuse EITHER product into the add -- it did so differently in the even and the odd copies of an unrolled trip,
+// so the last bit of a point depended on the parity of (x - block start): x-chunks of odd length, or two instantiations of one
+// source, gave results 1 ulp apart at ~1 % of the points (round 3, profiles/r3_bitexact).  With the operation written out every
+// copy rounds the same way, whatever the chunking.
+template <class V, class T>
+__device__ __forceinline__ V fmacc(V v, T ck, V s) { return __builtin_elementwise_fma(v, V(ck), s); }
+
 // compile-time loop: f(integral_constant<int,0>) ... f(integral_constant<int,N-1>)
 template <class F, int... I>
 __host__ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {

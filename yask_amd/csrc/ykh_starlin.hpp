@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
                     constexpr int k = decltype(kc)::value + 1;
                     const T ck = lin_coef_of<P, -k, 0, 0>(cs);
                     constexpr int qi = rot<NP>(PH, NP - 1 - k);
-                    sum[j] += pq[qi][j] * ck;
+                    sum[j] = fmacc(pq[qi][j], ck, sum[j]);
                 });
             });
             // ... the thread's own rows are y-neighbours of each other (registers) ...
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
                     if constexpr (dy != 0 && dy >= -YL && dy <= C::YH) {
                         if constexpr (lin_coef<P>(0, dy, 0) != 0.0) {
                             const T ck = lin_coef_of<P, 0, dy, 0>(cs);
-                            sum[j] += c[decltype(j2c)::value] * ck;
+                            sum[j] = fmacc(c[decltype(j2c)::value], ck, sum[j]);
                         }
                     }
                 });
@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
                                 if constexpr (dy >= -YL && dy <= C::YH) {
                                     if constexpr (lin_coef<P>(0, dy, 0) != 0.0) {
                                         const T ck = lin_coef_of<P, 0, dy, 0>(cs);
-                                        sum[j] += t[b][i] * ck;
+                                        sum[j] = fmacc(t[b][i], ck, sum[j]);
                                     }
                                 }
                             });
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
                         if constexpr (dz != 0 && lin_coef<P>(0, 0, dz) != 0.0) {
                             constexpr int e = ZLV * VZ + dz;
                             const T ck = lin_coef_of<P, 0, 0, dz>(cs);
-                            sum[j] += zshiftn<T, VZ, e % VZ>(zw[e / VZ], zw[(e / VZ + 1) < C::NW ? (e / VZ + 1) : e / VZ]) * ck;
+                            sum[j] = fmacc(zshiftn<T, VZ, e % VZ>(zw[e / VZ], zw[(e / VZ + 1) < C::NW ? (e / VZ + 1) : e / VZ]), ck, sum[j]);
                         }
                     });
                     pin_reg(sum[j]);
@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
                 constexpr int k = decltype(kc)::value + 1;
                 const T ck = lin_coef_of<P, k, 0, 0>(cs);
                 constexpr int ai = rot<NA>(PH, NA - 1 - k);
-                acc[ai][j] += c[j] * ck;
+                acc[ai][j] = fmacc(c[j], ck, acc[ai][j]);
             });
             // ---- output plane xo = xin - XH is complete
             V cj[MAX_GROUPS], out[MAX_GROUPS];

@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin2_kernel(const PartArgs
                 static_for<XL>([&](auto kc) {
                     constexpr int k = decltype(kc)::value + 1;
                     constexpr T ck = T(lin_coef<P>(-k, 0, 0));
-                    sum[j] += pq[NP - 1 - k][j] * ck;
+                    sum[j] = fmacc(pq[NP - 1 - k][j], ck, sum[j]);
                 });
             });
             static_for<RY>([&](auto jc) {
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin2_kernel(const PartArgs
                     if constexpr (dy != 0 && dy >= -YL && dy <= YH) {
                         if constexpr (lin_coef<P>(0, dy, 0) != 0.0) {
                             constexpr T ck = T(lin_coef<P>(0, dy, 0));
-                            sum[j] += c[decltype(j2c)::value] * ck;
+                            sum[j] = fmacc(c[decltype(j2c)::value], ck, sum[j]);
                         }
                     }
                 });
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin2_kernel(const PartArgs
                             if constexpr (dy >= -YL && dy <= YH) {
                                 if constexpr (lin_coef<P>(0, dy, 0) != 0.0) {
                                     constexpr T ck = T(lin_coef<P>(0, dy, 0));
-                                    sum[j] += t[b][i] * ck;
+                                    sum[j] = fmacc(t[b][i], ck, sum[j]);
                                 }
                             }
                         });
@@ -244,8 +244,8 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin2_kernel(const PartArgs
                         constexpr int e = ZLV * VZ + dz;
                         constexpr T ck = T(lin_coef<P>(0, 0, dz));
                         constexpr int hi = (e / VZ + 1) < C::NW ? (e / VZ + 1) : e / VZ;
-                        sumA[j] += zshiftn<T, VZ, e % VZ>(zwA[e / VZ], zwA[hi]) * ck;
-                        sumB[j] += zshiftn<T, VZ, e % VZ>(zwB[e / VZ], zwB[hi]) * ck;
+                        sumA[j] = fmacc(zshiftn<T, VZ, e % VZ>(zwA[e / VZ], zwA[hi]), ck, sumA[j]);
+                        sumB[j] = fmacc(zshiftn<T, VZ, e % VZ>(zwB[e / VZ], zwB[hi]), ck, sumB[j]);
                     }
                 });
                 pin_reg(sumA[j]);
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin2_kernel(const PartArgs
                 static_for<XH>([&](auto kc) {
                     constexpr int k = decltype(kc)::value + 1;
                     constexpr T ck = T(lin_coef<P>(k, 0, 0));
-                    acc[NA - 1 - k][j] += c[j] * ck;
+                    acc[NA - 1 - k][j] = fmacc(c[j], ck, acc[NA - 1 - k][j]);
                 });
                 V cj[MAX_GROUPS], out[MAX_GROUPS];
                 LinAcc<C> la{pq[NP - 1 - XH][j], cj, out};
