@@ -171,6 +171,21 @@ def test_ssg_fast_division_is_an_option_and_the_exact_shapes_are_bit_identical(g
     assert 0.0 < worst <= 1e-6, worst
 
 
+def test_ssg_default_shapes_are_bit_identical_under_odd_x_chunks(gpu):
+    """The march kernels evaluate the generated expression with every operation pinned in the reference's order (no free choice of
+    which product to fuse): the x-chunk length, odd ones included, must not move a bit (cf. the starlin shapes' test above)."""
+    size, steps = (150, 64, 128), 3
+    runs = []
+    for opts in ("-hip_variant march_v4_z128_y16_nt_hr_ps_fd_t2_w2", "-hip_variant march_v4_z128_y16_nt_hr_ps_fd_t2_w2 -hip_xchunk 37",
+                 "-hip_variant march_v4_z128_y16_nt_hr_ps_fd_t2_w2 -hip_xchunk 51"):
+        s = make("ssg", size, opts)
+        s.run_solution(0, steps - 1)
+        runs.append({n: domain_slice(s, s.get_var(n), steps).copy() for n in O.SSG_FIELDS})
+        s.end_solution()
+    for n in O.SSG_FIELDS:
+        assert np.array_equal(runs[0][n], runs[1][n]) and np.array_equal(runs[0][n], runs[2][n]), n
+
+
 @pytest.mark.parametrize("name", [n for n in INDEX if INDEX[n]["stencil"] == "ssg" and "lattice_stride" not in INDEX[n]])
 def test_ssg_matches_reference_golden(gpu, name):
     meta = INDEX[name]

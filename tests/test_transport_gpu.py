@@ -234,13 +234,14 @@ def test_exchange_halos_after_a_change_on_one_rank_only(gpu, transport, monkeypa
     assert parts[1] == 123.5
 
 
-SCHEDULES = {"planned": "", "planned_greedy": "-hip_plan_mode 1 -hip_shell_pct 30", "planned_uniform_ipc": "-hip_plan_mode 2",
+SCHEDULES = {"planned": "", "planned_one_launch_signal": "-no-hip_planned_split", "planned_pack_on_comm_stream_ipc": "-no-hip_inline_pack", "planned_greedy": "-hip_plan_mode 1 -hip_shell_pct 30 -no-hip_planned_split",
+             "planned_uniform_ipc": "-hip_plan_mode 2",
              "slabs0": "-no-hip_planned_launch -hip_ext_streams 0", "slabs1": "-no-hip_planned_launch -hip_ext_streams 1",
              "slabs2": "-no-hip_planned_launch -hip_ext_streams 2"}
 
 
 @pytest.mark.parametrize("stencil,g,steps,sched", [("iso3dfd", (48, 40, 72), 3, k) for k in SCHEDULES] +
-                         [("ssg", (32, 28, 40), 2, k) for k in ("planned", "planned_greedy", "slabs0")])
+                         [("ssg", (32, 28, 40), 2, k) for k in ("planned", "planned_one_launch_signal", "planned_greedy", "slabs0")])
 def test_eight_ranks_on_the_compact_2x2x2_grid(gpu, stencil, g, steps, sched, monkeypatch):
     """BASELINE.json configs[3]/[4] run on the reference's default rank grid for 8 ranks, 2x2x2
     (get_compact_factors, src/common/tuple.cpp:355-430): 3 face neighbours per rank for iso3dfd; ssg's `mu` is read

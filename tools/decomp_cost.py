@@ -29,6 +29,8 @@ SSG_CASES = [
 CONFIGS = [  # label, options
     ("planned rounds pct55 (default)", "-hip_planned_launch -hip_shell_pct 55 -hip_plan_mode 0"),
     ("planned rounds pct35", "-hip_planned_launch -hip_shell_pct 35 -hip_plan_mode 0"),
+    ("planned, one round if shortest (pct100: descriptors + signals, no early shell)", "-hip_planned_launch -hip_shell_pct 100 -hip_plan_mode 0"),
+    ("planned rounds pct55, blocks in regular-launch order (shell not first)", "-hip_planned_launch -hip_shell_pct 55 -hip_plan_mode 3"),
     ("first planner: thin x slabs + per-CU budgets", "-hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 1"),
     ("first planner: uniform interior chunks", "-hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 2"),
     ("slabs, interior in 2 launches (round 2 default)", "-no-hip_planned_launch -hip_overlap_splits 2"),
@@ -51,14 +53,22 @@ def main():
     cases = SSG_CASES if args.stencil == "ssg" else CASES
     configs = CONFIGS
     if args.quick:
-        cases, configs = cases[:2], [CONFIGS[0], CONFIGS[5], CONFIGS[6]]
+        cases, configs = cases[:2], [CONFIGS[0], CONFIGS[2], CONFIGS[3], CONFIGS[7], CONFIGS[8]]
     out = []
+    ramped = False
     for name, size, lo, hi in cases:
         for label, opts in configs:
             s = fac.new_solution(fac.new_env())
             s.set_overall_domain_size_vec(list(size))
             assert s.apply_command_line_options("-no-auto_tune " + opts) == ""
             s.prepare_solution()
+            if not ramped:          # a box that idled is at low clocks: ~1.5 s of plain steps before the first measurement
+                import time
+                t0, t = time.perf_counter(), 0
+                while time.perf_counter() - t0 < 1.5:
+                    s.run_solution(t, t + 19)
+                    t += 20
+                ramped = True
             for k, v in enumerate(s.get_vars()):
                 v.set_elements_hash(1.0, 0.1, hash_id=k)
             ext, inter, whole = s.time_decomposed_step(lo, hi, reps=args.reps)

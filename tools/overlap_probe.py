@@ -24,6 +24,8 @@ CASES = {  # name -> (global size, rank grid, rank played)
             ("ssg 512^3 / 8 GPUs 2x2x2: 256^3 block", (512, 512, 512), (2, 2, 2), 0)],
 }
 SCHEDULES = [("planned (rounds, shell first)", "-overlap_comms -hip_planned_launch"),
+             ("planned, pack on the comm stream (-no-hip_inline_pack)", "-overlap_comms -hip_planned_launch -no-hip_inline_pack"),
+             ("planned, one launch + device-side signal (-no-hip_planned_split)", "-overlap_comms -hip_planned_launch -no-hip_planned_split"),
              ("planned, shell by 35 %", "-overlap_comms -hip_planned_launch -hip_shell_pct 35"),
              ("slabs + interior (round 2)", "-overlap_comms -no-hip_planned_launch"),
              ("whole box, then exchange", "-no-overlap_comms")]
@@ -33,13 +35,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stencil", default="iso3dfd")
     ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--cases", type=int, default=99, help="only the first N cases")
+    ap.add_argument("--schedules", default="", help="only the schedules whose label contains this text")
+    ap.add_argument("--tag", default="")
     args = ap.parse_args()
     from yask_amd import yk_factory
     from yask_amd.kernel import yk_env
     yk_env.disable_debug_output()
     fac = yk_factory(args.stencil)
     out = []
-    for name, g, nr, rank in CASES[args.stencil]:
+    for name, g, nr, rank in CASES[args.stencil][:args.cases]:
         world = nr[0] * nr[1] * nr[2]
         local = [g[d] // nr[d] for d in range(3)]
         # reference: the same block as a one-rank job
@@ -54,7 +59,7 @@ def main():
         s.run_solution(10, 10 + args.steps - 1)
         one_ms = (time.perf_counter() - t0) / args.steps * 1e3
         s.end_solution()
-        for label, opts in SCHEDULES:
+        for label, opts in [x for x in SCHEDULES if args.schedules in x[0]]:
             env = fac.new_env()
             env.init_mirror(rank, world)
             s = fac.new_solution(env)
@@ -72,7 +77,7 @@ def main():
             st = s.get_stats()
             n = args.steps
             comm = st.get_halo_pack_secs() + st.get_halo_xfer_secs() + st.get_halo_unpack_secs()
-            rec = {"case": name, "schedule": label, "ms_per_step": round(ms, 4), "one_rank_block_ms_per_step": round(one_ms, 4),
+            rec = {"tag": args.tag, "case": name, "schedule": label, "ms_per_step": round(ms, 4), "one_rank_block_ms_per_step": round(one_ms, 4),
                    "vs_one_rank_block": round(ms / one_ms, 3),
                    "exterior_ms": round(st.get_exterior_secs() / n * 1e3, 4), "interior_ms": round(st.get_interior_secs() / n * 1e3, 4),
                    "pack_ms": round(st.get_halo_pack_secs() / n * 1e3, 4), "copy_ms": round(st.get_halo_xfer_secs() / n * 1e3, 4),
@@ -84,7 +89,7 @@ def main():
             s.end_solution()
     od = Path(__file__).resolve().parents[1] / "gpurun_out"
     od.mkdir(exist_ok=True)
-    json.dump(out, open(od / f"overlap_probe_{args.stencil}.json", "w"), indent=1)
+    json.dump(out, open(od / f"overlap_probe_{args.stencil}{args.tag}.json", "w"), indent=1)
 
 
 if __name__ == "__main__":

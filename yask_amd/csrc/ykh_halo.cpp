@@ -116,6 +116,76 @@ static size_t collect_slabs(Solution& s, const std::vector<Slab>& slabs, void* b
     return ofs;
 }
 
+// The messages of one exchange and their packing: every dirty (var, slot) slab of every neighbour goes into that neighbour's send
+// buffer (one vectorised launch for all of them, on `st`); x faces of "direct" neighbours travel straight from the var's planes.
+void Solution::exchange_build_and_pack(hipStream_t st) {
+    std::vector<HaloMsg>& msgs = pending_msgs;
+    std::vector<HaloSeg> segs;
+    for (auto& x : xfers) {
+        if (x->direct) {
+            // one message per dirty (var, slot): whole planes (with their y/z pads) straight from / into the var
+            x->send_now = x->recv_now = 0;
+            for (size_t i = 0; i < x->send.size(); i++) {
+                const Slab &ss = x->send[i], &rs = x->recv[i];
+                Var& v = *vars[ss.var];
+                for (int slot = 0; slot < v.nslots; slot++) {
+                    if (!v.dirty[slot]) continue;
+                    auto plane_ptr = [&](idx_t xl) {
+                        return (char*)v.dptr + ((size_t)slot * v.slot_elems + v.origin_elems + xl * v.stride[0] -
+                                                v.pad_l[1] * v.stride[1] - v.pad_l[2] * v.stride[2]) * elem_bytes();
+                    };
+                    HaloMsg m;
+                    m.peer = x->nb.rank;
+                    m.send_buf = plane_ptr(ss.lo[0]); m.send_bytes = (size_t)(ss.n[0] * v.stride[0]) * elem_bytes();
+                    m.recv_buf = plane_ptr(rs.lo[0]); m.recv_bytes = (size_t)(rs.n[0] * v.stride[0]) * elem_bytes();
+                    m.tag = (x->nb.ofs[0] + 1) * 9 + 4;
+                    msgs.push_back(m);
+                    x->send_now += m.send_bytes; x->recv_now += m.recv_bytes;
+                }
+            }
+            continue;
+        }
+        x->send_now = collect_slabs(*this, x->send, x->send_buf, segs);
+        // receive size: same rule evaluated on my recv slabs (neighbour's dirty flags mirror mine)
+        size_t r = 0;
+        for (const Slab& sl : x->recv) {
+            Var& v = *vars[sl.var];
+            for (int slot = 0; slot < v.nslots; slot++)
+                if (v.dirty[slot]) r += (size_t)sl.elems * elem_bytes();
+        }
+        x->recv_now = r;
+        if (!x->send_now && !x->recv_now) continue;
+        HaloMsg m;
+        m.peer = x->nb.rank;
+        m.send_buf = x->send_buf; m.recv_buf = x->recv_buf;
+        m.send_bytes = x->send_now; m.recv_bytes = x->recv_now;
+        // tag encodes the direction so that both messages between a pair of ranks are distinct
+        m.tag = (x->nb.ofs[0] + 1) * 9 + (x->nb.ofs[1] + 1) * 3 + (x->nb.ofs[2] + 1);
+        msgs.push_back(m);
+    }
+    launch_halo_move(segs, /*pack=*/true, elem_bytes(), st);
+}
+
+// Planned launch in two parts (launch_planned, planned_split): called between them ON THE COMPUTE STREAM.  The second part's blocks
+// take every CU the moment the first part ends, and a pack kernel on the comm stream then finds no wave slot until they are done
+// (measured: its 0.02 ms became 0.21 ms, the whole second part, and the exchange was not hidden at all, tools/overlap_probe.py):
+// packing in line costs the launch those 0.02 ms and lets the transfer run beside the second part.  The send buffers are free:
+// the compute stream has waited for the previous exchange's unpack, which the comm stream ran behind its sends.
+void Solution::exchange_prepack(hipStream_t st) {
+    prepacked_ = false;
+    if (env->nranks <= 1 || xfers.empty() || !env->exch_start) return;
+    bool any = false;
+    for (auto& v : vars)
+        for (char d : v->dirty) any |= (d != 0);
+    pending_msgs.clear();
+    prepacked_ = true;
+    if (!any) return;
+    phase_mark(PH_EXT1, st);
+    phase_mark(PH_PACK0, st);
+    exchange_build_and_pack(st);
+    phase_mark(PH_PACK1, st);
+}
+
 // start_only : pack + begin transport on the comm stream (after everything queued on the compute stream);
 // finish_only: wait for arrival, unpack, and make the compute stream wait for the unpack.
 void Solution::exchange_halos(idx_t /*t_written*/, int /*stage*/, bool start_only, bool finish_only) {
@@ -123,71 +193,39 @@ void Solution::exchange_halos(idx_t /*t_written*/, int /*stage*/, bool start_onl
     if (!env->exch_start) YKH_THROW("multi-rank solution has no halo-exchange transport installed in its env");
     std::vector<HaloMsg>& msgs = pending_msgs;      // messages between a start and the matching finish
     if (!finish_only) {
-        bool any = false;
-        for (auto& v : vars)
-            for (char d : v->dirty) any |= (d != 0);
-        msgs.clear();
-        const bool signalled = sig_pending;
-        sig_pending = false;
-        if (!any) return;
-        if (signalled) {
-            // planned launch: the data the neighbours need comes from the launch's shell blocks, which publish an epoch when the
-            // last of them has finished (block_done(), ykh_device.hpp) -- the comm stream waits for THAT, not for the launch
-            const unsigned* wp = sig_dev + 1;
-            const unsigned wv = sig_epoch;
-            launch_wait_words(1, &wp, &wv, sig_dev + 2, 20.0, comm_stream);
-            phase_mark(PH_EXT1, comm_stream);         // = the exterior is done (interior_secs then runs from here to PH_INT1)
+        const bool signalled = sig_pending, evented = shell_event_pending, prepacked = prepacked_;
+        sig_pending = shell_event_pending = prepacked_ = false;
+        if (prepacked) {
+            // (the messages were built and packed on the compute stream between the two parts of a planned launch; ev_shell was
+            //  recorded behind the pack)
+            if (msgs.empty()) return;
+            YKH_HIP(hipStreamWaitEvent(comm_stream, ev_shell, 0));
         } else {
-            // comm stream waits for the kernels that produced the data
-            YKH_HIP(hipEventRecord(ev_a, compute_stream));
-            YKH_HIP(hipStreamWaitEvent(comm_stream, ev_a, 0));
-        }
-        phase_mark(PH_PACK0, comm_stream);
-        std::vector<HaloSeg> segs;
-        for (auto& x : xfers) {
-            if (x->direct) {
-                // one message per dirty (var, slot): whole planes (with their y/z pads) straight from / into the var
-                x->send_now = x->recv_now = 0;
-                for (size_t i = 0; i < x->send.size(); i++) {
-                    const Slab &ss = x->send[i], &rs = x->recv[i];
-                    Var& v = *vars[ss.var];
-                    for (int slot = 0; slot < v.nslots; slot++) {
-                        if (!v.dirty[slot]) continue;
-                        auto plane_ptr = [&](idx_t xl) {
-                            return (char*)v.dptr + ((size_t)slot * v.slot_elems + v.origin_elems + xl * v.stride[0] -
-                                                    v.pad_l[1] * v.stride[1] - v.pad_l[2] * v.stride[2]) * elem_bytes();
-                        };
-                        HaloMsg m;
-                        m.peer = x->nb.rank;
-                        m.send_buf = plane_ptr(ss.lo[0]); m.send_bytes = (size_t)(ss.n[0] * v.stride[0]) * elem_bytes();
-                        m.recv_buf = plane_ptr(rs.lo[0]); m.recv_bytes = (size_t)(rs.n[0] * v.stride[0]) * elem_bytes();
-                        m.tag = (x->nb.ofs[0] + 1) * 9 + 4;
-                        msgs.push_back(m);
-                        x->send_now += m.send_bytes; x->recv_now += m.recv_bytes;
-                    }
-                }
-                continue;
+            bool any = false;
+            for (auto& v : vars)
+                for (char d : v->dirty) any |= (d != 0);
+            msgs.clear();
+            if (!any) return;
+            if (evented) {
+                // planned launch in two parts: the comm stream waits for the event behind the shell's rounds
+                YKH_HIP(hipStreamWaitEvent(comm_stream, ev_shell, 0));
+                phase_mark(PH_EXT1, comm_stream);
+            } else if (signalled) {
+                // planned launch: the data the neighbours need comes from the launch's shell blocks, which publish an epoch when the
+                // last of them has finished (block_done(), ykh_device.hpp) -- the comm stream waits for THAT, not for the launch
+                const unsigned* wp = sig_dev + 1;
+                const unsigned wv = sig_epoch;
+                launch_wait_words(1, &wp, &wv, sig_dev + 2, 20.0, comm_stream);
+                phase_mark(PH_EXT1, comm_stream);         // = the exterior is done (interior_secs then runs from here to PH_INT1)
+            } else {
+                // comm stream waits for the kernels that produced the data
+                YKH_HIP(hipEventRecord(ev_a, compute_stream));
+                YKH_HIP(hipStreamWaitEvent(comm_stream, ev_a, 0));
             }
-            x->send_now = collect_slabs(*this, x->send, x->send_buf, segs);
-            // receive size: same rule evaluated on my recv slabs (neighbour's dirty flags mirror mine)
-            size_t r = 0;
-            for (const Slab& sl : x->recv) {
-                Var& v = *vars[sl.var];
-                for (int slot = 0; slot < v.nslots; slot++)
-                    if (v.dirty[slot]) r += (size_t)sl.elems * elem_bytes();
-            }
-            x->recv_now = r;
-            if (!x->send_now && !x->recv_now) continue;
-            HaloMsg m;
-            m.peer = x->nb.rank;
-            m.send_buf = x->send_buf; m.recv_buf = x->recv_buf;
-            m.send_bytes = x->send_now; m.recv_bytes = x->recv_now;
-            // tag encodes the direction so that both messages between a pair of ranks are distinct
-            m.tag = (x->nb.ofs[0] + 1) * 9 + (x->nb.ofs[1] + 1) * 3 + (x->nb.ofs[2] + 1);
-            msgs.push_back(m);
+            phase_mark(PH_PACK0, comm_stream);
+            exchange_build_and_pack(comm_stream);
+            phase_mark(PH_PACK1, comm_stream);
         }
-        launch_halo_move(segs, /*pack=*/true, elem_bytes(), comm_stream);
-        phase_mark(PH_PACK1, comm_stream);
         for (const HaloMsg& m : msgs) {
             stats.halo_bytes_sent += (idx_t)m.send_bytes; stats.halo_bytes_recv += (idx_t)m.recv_bytes;
             stats.halo_msgs_sent += m.send_bytes ? 1 : 0;

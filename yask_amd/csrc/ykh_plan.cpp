@@ -266,6 +266,15 @@ static BlockPlan plan_rounds(const BlockPlanIn& in) {
         }
         std::vector<BlockDesc> all = p1;
         all.insert(all.end(), p2.begin(), p2.end());
+        if (in.mode == 3) {
+            // diagnostic: the same blocks in the order of a regular launch (chunk-major), shell blocks NOT first -- what does the
+            // shell-first order cost by itself?  (tools/decomp_cost.py)
+            all.clear();
+            for (idx_t c = 0; c < k; c++) {
+                for (auto& d : p1) if (d.x0 == (int)(nx * c / k)) all.push_back(d);
+                for (auto& d : p2) if (d.x0 == (int)(nx * c / k)) all.push_back(d);
+            }
+        }
         // simulate the dispatch; within each round of ncu blocks, deal the blocks over the XCD strips
         CuLine cl(in.ncu);
         idx_t sd = 0;
@@ -331,7 +340,7 @@ BlockPlan plan_blocks(const BlockPlanIn& in) {
     BlockPlan out;
     const idx_t nx = in.n[0], ny = in.n[1], nz = in.n[2];
     if (nx < 1 || ny < 1 || nz < 1 || in.ty < 1 || in.tz < 1 || in.ncu < 1) throw PlanError("plan_blocks: bad box or tile");
-    if (in.mode == 0) return plan_rounds(in);
+    if (in.mode == 0 || in.mode == 3) return plan_rounds(in);
     const idx_t o = std::max<idx_t>(0, in.overhead), minlen = std::max<idx_t>(1, in.min_len);
     auto desc = [](const TileBox& tb, idx_t x0, idx_t x1, int flags, idx_t start) {
         BlockDesc d;

@@ -453,17 +453,29 @@ public:
     idx_t shell_pct = 55;              // -hip_shell_pct <n>: the shell should be done after n % of the launch (55: two rounds of equal
                                        // blocks, the shell in the first; lower = more rounds = more chunk prologues)
     idx_t plan_mode = 0;               // -hip_plan_mode <0|1|2>: 0 rounds of equal blocks (default); 1 / 2 the first planner (A/B only)
-    struct LaunchPlan { std::string key; BlockPlan plan; BlockDesc* dev = nullptr; };
+    struct LaunchPlan { std::string key; BlockPlan plan; BlockDesc* dev = nullptr; size_t cut = 0; };      // cut: end of the round that holds the last shell block
     std::vector<std::unique_ptr<LaunchPlan>> launch_plans;
     unsigned* sig_dev = nullptr;       // [0] finished signalling blocks, [1] published epoch, [2] a waiter gave up (error), [3] unused
     unsigned sig_count = 0, sig_epoch = 0;
     bool sig_pending = false;          // the launch just issued publishes sig_epoch: exchange_halos() waits for it on the comm stream
     bool sig_used = false;             // some launch of this run() signalled: run() checks the error word at the end
+    // -[no-]hip_planned_split (default on): the planned launch goes out as TWO launches, cut at the end of the round that holds the last
+    // shell block, with an event between them that releases the exchange -- no wave polling a word.  The one-wave waiter of the
+    // one-launch form takes a wave slot on some CU, and a marching block needs ALL registers of a CU (8 waves x 256 VGPRs): with
+    // the waiter resident the launch has 255 CUs, the 256th block of a round runs alone afterwards (+0.1 ms on a 0.46 ms launch,
+    // measured: tools/overlap_probe.py, profiles/r3_overlap).
+    bool planned_split = true;
+    bool shell_event_pending = false;  // ev_shell was recorded behind the shell part of the launch just issued
+    hipEvent_t ev_shell = nullptr;
+    bool inline_pack = true;           // -[no-]hip_inline_pack: pack the halos between the two parts, on the compute stream (exchange_prepack)
+    bool prepacked_ = false;           // exchange_prepack() built and packed the messages of the exchange about to start
+    void exchange_build_and_pack(hipStream_t st);
+    void exchange_prepack(hipStream_t st);
     int planned_part(const StageMeta& sm) const;        // the stage's one part if it can run as a planned launch, else -1
     int planned_variant_of(int part) const;             // the kernel shape whose descriptor-reading twin runs the part's planned launches, or -1
     mutable std::vector<int> planned_cache_;             // ... remembered per part (-2: not looked up yet); cleared with the launch plans
     LaunchPlan* get_launch_plan(int part, const bool* has_lo, const bool* has_hi, bool wide_shell = false);
-    void launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hipStream_t s);
+    void launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hipStream_t s, bool inline_pack = false);
     void drop_launch_plans();
     void neighbor_sides(bool* has_lo, bool* has_hi) const;
     void time_decomposed_step(const bool* has_lo, const bool* has_hi, int reps, float* ms3);

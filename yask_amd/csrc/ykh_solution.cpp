@@ -117,6 +117,7 @@ Solution::Solution(std::shared_ptr<Env> e, const SolnImpl& im) : env(e), impl(im
     }
     own_streams = true;
     YKH_HIP(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
+    YKH_HIP(hipEventCreateWithFlags(&ev_shell, hipEventDisableTiming));
     YKH_HIP(hipEventCreateWithFlags(&ev_b, hipEventDisableTiming));
 }
 
@@ -129,6 +130,7 @@ Solution::~Solution() {
     scratch_vars.clear();
     var_map.clear();
     if (ev_a) (void)hipEventDestroy(ev_a);
+    if (ev_shell) (void)hipEventDestroy(ev_shell);
     if (ev_b) (void)hipEventDestroy(ev_b);
     if (ev_stage) (void)hipEventDestroy(ev_stage);
     for (auto e : ext_events) if (e) (void)hipEventDestroy(e);
@@ -220,7 +222,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                                "bind_inner_threads", "bundle_allocs", "init_scratch_vars", "auto_tune",
                                "allow_addl_padding", "round_up_temporal_angles", "print_suffixes", "verbose",
                                "exchange_halos", "auto_tune_each_stage", "trace", "hip_direct_halo", "hip_thin_slab_point_kernel", "hip_round_launches",
-                               "hip_step_timers", "hip_phase_timers", "hip_fast_div", "hip_planned_launch", "hip_wf_ext_always"};
+                               "hip_step_timers", "hip_phase_timers", "hip_fast_div", "hip_planned_launch", "hip_planned_split", "hip_inline_pack", "hip_wf_ext_always"};
     const char* int_opts[] = {"hip_shell_pct", "hip_plan_mode", "hip_placement_trials", "hip_var_skew", "hip_step_graphs", "hip_pitch_extra", "hip_ext_streams", "hip_comm_cus", "hip_fuse_steps", "hip_overlap_splits", "min_exterior", "max_threads", "outer_threads", "inner_threads", "numa_pref",
                               "auto_tune_radius", "thread_divisor", "block_threads", "hip_xchunk", "device_thread_limit"};
     const char* dbl_opts[] = {"auto_tune_trial_secs"};
@@ -245,6 +247,8 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                     else if (b == "hip_step_timers") step_timers = val;
                     else if (b == "hip_phase_timers") phase_timers = val;
                     else if (b == "hip_planned_launch") planned_launch = val;
+                    else if (b == "hip_planned_split") planned_split = val;
+                    else if (b == "hip_inline_pack") inline_pack = val;
                     else if (b == "hip_wf_ext_always") { wf_ext_always = val; invalidate(); }
                     else if (b == "trace") env->trace = val;
                     else if (b == "hip_direct_halo") { direct_halo = val; invalidate(); }
@@ -267,7 +271,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                 handled = true;
                 if (opt == "min_exterior") { min_exterior = n; drop_launch_plans(); }
                 else if (opt == "hip_shell_pct") { shell_pct = std::min<idx_t>(95, std::max<idx_t>(5, n)); drop_launch_plans(); }
-                else if (opt == "hip_plan_mode") { plan_mode = std::min<idx_t>(2, std::max<idx_t>(0, n)); drop_launch_plans(); }
+                else if (opt == "hip_plan_mode") { plan_mode = std::min<idx_t>(3, std::max<idx_t>(0, n)); drop_launch_plans(); }
                 else if (opt == "hip_xchunk") xchunk_override = n;
                 else if (opt == "hip_overlap_splits") overlap_splits = std::max<idx_t>(1, n);
                 else if (opt == "hip_fuse_steps") fuse_steps = n;
@@ -382,11 +386,15 @@ std::string Solution::get_command_line_help() const {
           " -[no-]hip_round_launches          more tiles than CUs: one launch per CU-filling round of tile rows (default on)\n"
           " -[no-]hip_direct_halo             x-face halos of full-dim vars are sent/received in place (default on)\n"
           " -[no-]hip_thin_slab_point_kernel  thin y/z exterior slabs run on the point kernel (default on)\n"
+          " -[no-]hip_planned_split           planned launches go out as two launches with an event behind the shell's rounds (default on;\n"
+          "                                   off: one launch, the exchange released by a device-side signal that a resident wave polls)\n"
+          " -[no-]hip_inline_pack             ... and the halos are packed between the two, on the compute stream (default on)\n"
           " -[no-]hip_planned_launch          decomposed runs: the rank box as ONE launch of the marching kernel, shell blocks first,\n"
           "                                   the exchange released from the device when they are done (default on; off: exterior\n"
           "                                   slabs, then the interior in -hip_overlap_splits launches)\n"
           " -hip_shell_pct <n>                planned launches: the shell is to be done after n % of the launch (default 55: two rounds)\n"
-          " -hip_plan_mode <0|1|2>            planned launches: 0 = rounds of equal blocks, shell first (default); 1 / 2 = the first planner\n"
+          " -hip_plan_mode <0|1|2|3>          planned launches: 0 = rounds of equal blocks, shell first (default); 1 / 2 = the first planner;\n"
+          "                                   3 = the blocks of 0 in the order of a regular launch (diagnostic: the exchange starts late)\n"
           "                                   (thin x slabs, per-CU budgets / uniform interior chunks; measured slower, kept for A/B)\n"
           " -hip_overlap_splits <n>           slab schedule: interior launches per step when halos are overlapped (default 1)\n"
           " -hip_ext_streams <0|1|2>          exterior slabs: 0 one after another (default), 1 side by side on their own streams,\n"
@@ -1075,10 +1083,15 @@ void Solution::time_decomposed_step(const bool* has_lo, const bool* has_hi, int 
                 const StageMeta& sm = meta->stages[st];
                 LaunchPlan* lp = get_launch_plan(planned_part(sm), has_lo, has_hi);
                 launch_planned(planned_part(sm), r + 1, *lp, true, compute_stream);
-                sig_pending = false;
-                const unsigned* wp = sig_dev + 1;
-                const unsigned wv = sig_epoch;
-                launch_wait_words(1, &wp, &wv, sig_dev + 2, 20.0, comm_stream);
+                if (shell_event_pending) {
+                    shell_event_pending = false;
+                    YKH_HIP(hipStreamWaitEvent(comm_stream, ev_shell, 0));
+                } else {
+                    sig_pending = false;
+                    const unsigned* wp = sig_dev + 1;
+                    const unsigned wv = sig_epoch;
+                    launch_wait_words(1, &wp, &wv, sig_dev + 2, 20.0, comm_stream);
+                }
                 if (st == meta->n_stages - 1) YKH_HIP(hipEventRecord(e[1], comm_stream));
             }
             YKH_HIP(hipEventRecord(e[2], compute_stream));
@@ -1189,14 +1202,35 @@ Solution::LaunchPlan* Solution::get_launch_plan(int part, const bool* has_lo, co
         fprintf(stderr, "planned launch %s: %zu blocks (%lld signalling), simulated shell done at %lld, end at %lld, undivided %lld plane-iterations\n",
                 key.c_str(), lp->plan.blocks.size(), (long long)lp->plan.n_signal, (long long)lp->plan.shell_done,
                 (long long)lp->plan.makespan, (long long)lp->plan.undivided);
+    {
+        // where the shell ends: behind the last signalling block, rounded up to whole rounds of CUs (the blocks of a round end together)
+        size_t last = 0;
+        for (size_t i = 0; i < lp->plan.blocks.size(); i++) if (lp->plan.blocks[i].flags & BLOCK_SIGNALS) last = i + 1;
+        const size_t ncu = (size_t)std::max(1, env->num_cus);
+        lp->cut = std::min(lp->plan.blocks.size(), (last + ncu - 1) / ncu * ncu);
+    }
     launch_plans.push_back(std::move(lp));
     return launch_plans.back().get();
 }
-void Solution::launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hipStream_t s) {
+void Solution::launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hipStream_t s, bool with_pack) {
     const KernelVariant& kv = impl.parts[part].variants[planned_variant_of(part)];
     PartArgs a;
     fill_part_args(part, t, rank_box(), a);
     a.blk = lp.dev;
+    if (signal && lp.plan.n_signal > 0 && planned_split) {
+        // two launches, an event between them (see planned_split): the shell's rounds, then the rest
+        kv.launch_desc(a, dim3((unsigned)lp.cut, 1, 1), s);
+        YKH_HIP(hipGetLastError());
+        if (with_pack && inline_pack) exchange_prepack(s);
+        YKH_HIP(hipEventRecord(ev_shell, s));
+        shell_event_pending = true;
+        if (lp.cut < lp.plan.blocks.size()) {
+            a.blk = lp.dev + lp.cut;
+            kv.launch_desc(a, dim3((unsigned)(lp.plan.blocks.size() - lp.cut), 1, 1), s);
+            YKH_HIP(hipGetLastError());
+        }
+        return;
+    }
     if (signal && lp.plan.n_signal > 0) {
         if (!sig_dev) {
             // (zeroed before anything can poll it: a waiter on the comm stream must not read what hipMalloc left there)
@@ -1605,7 +1639,7 @@ void Solution::run(idx_t first_step, idx_t last_step) {
     }
     phase_used = 0;
     cur_phase = nullptr;
-    sig_pending = false;
+    sig_pending = shell_event_pending = prepacked_ = false;
     sig_used = false;
     // Wave-front temporal tiling (-Mbt / -bt > 1): groups of steps go slab by slab (run_wavefront below).  Single rank only:
     // with neighbours the halos would have to be wf_steps x wider (the reference extends them, setup.cpp:863-1020).
@@ -1687,8 +1721,8 @@ void Solution::run(idx_t first_step, idx_t last_step) {
                 // (the reference's exterior-first order, context.cpp:377-478, without separate launches)
                 LaunchPlan* lp = get_launch_plan(pl_part, lo, hi);
                 phase_mark(PH_EXT0, compute_stream);
-                launch_planned(pl_part, t, *lp, /*signal=*/true, compute_stream);
-                note_stage_written(sm, t);
+                note_stage_written(sm, t);          // (host bookkeeping: the dirty flags the in-line pack goes by)
+                launch_planned(pl_part, t, *lp, /*signal=*/true, compute_stream, /*with_pack=*/true);
                 exchange_halos(t, st, /*start_only=*/true, false);       // (marks PH_EXT1 on the comm stream, after its wait)
                 phase_mark(PH_INT1, compute_stream);
                 exchange_halos(t, st, false, /*finish_only=*/true);
