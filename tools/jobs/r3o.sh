@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU job r3o: does the pack kernel's competition for CUs explain the longer planned launch in the full schedule? (diagnostic knobs)
+# (the YKH_DEBUG_SKIP_PACK / YKH_PACK_BLOCKS knobs this job used were removed from launch_halo_move() after the measurement)
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r3o; mkdir -p $O; cd $R
 run() { tag=$1; shift; env "$@" timeout 200 python tools/overlap_probe.py --cases 2 --schedules "planned (rounds" --tag _$tag 2>&1 | grep '^{' | python -c "
 import sys,json

@@ -296,11 +296,7 @@ void launch_halo_move(const std::vector<HaloSeg>& segs, bool pack, int elem_byte
         }
         if (a.nseg == 0 || a.total == 0) continue;
         const unsigned long long want = (a.total + 255) / 256;
-        // (diagnostic knobs of tools/overlap_probe.py: YKH_PACK_BLOCKS caps the grid, YKH_DEBUG_SKIP_PACK drops the pack launches)
-        static const long cap = getenv("YKH_PACK_BLOCKS") ? atol(getenv("YKH_PACK_BLOCKS")) : 16384;
-        static const bool skip_pack = getenv("YKH_DEBUG_SKIP_PACK") != nullptr;
-        if (pack && skip_pack) continue;
-        const unsigned blocks = (unsigned)std::min<unsigned long long>(want, (unsigned long long)std::max(1L, cap));       // (grid-strided beyond that)
+        const unsigned blocks = (unsigned)std::min<unsigned long long>(want, 16384);       // (grid-strided beyond that)
         if (pack) hipLaunchKernelGGL(halo_move_k<true>, dim3(blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(halo_move_k<false>, dim3(blocks), dim3(256), 0, st, a);
         YKH_HIP(hipGetLastError());
