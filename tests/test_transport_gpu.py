@@ -234,7 +234,7 @@ def test_exchange_halos_after_a_change_on_one_rank_only(gpu, transport, monkeypa
     assert parts[1] == 123.5
 
 
-SCHEDULES = {"planned": "", "planned_one_launch_signal": "-no-hip_planned_split", "planned_pack_on_comm_stream_ipc": "-no-hip_inline_pack", "planned_greedy": "-hip_plan_mode 1 -hip_shell_pct 30 -no-hip_planned_split",
+SCHEDULES = {"planned": "", "planned_one_launch_signal": "-no-hip_planned_split", "planned_inline_pack_ipc": "-hip_inline_pack", "planned_greedy": "-hip_plan_mode 1 -hip_shell_pct 30 -no-hip_planned_split",
              "planned_uniform_ipc": "-hip_plan_mode 2",
              "slabs0": "-no-hip_planned_launch -hip_ext_streams 0", "slabs1": "-no-hip_planned_launch -hip_ext_streams 1",
              "slabs2": "-no-hip_planned_launch -hip_ext_streams 2"}

@@ -34,6 +34,44 @@ __global__ void __launch_bounds__(64) poll_word(const unsigned* w, unsigned v, u
     if (threadIdx.x == 0) *out = ok ? 1u : 2u;
 }
 __global__ void mark(unsigned* out, unsigned v) { *out = v; }
+// a pack-like kernel: 256-thread workgroups (one wave per SIMD) at a given VGPR count, each busy for a few microseconds
+template <int NV>
+__global__ void __launch_bounds__(256) small(unsigned long long ticks) {
+    if (NV > 16) asm volatile("v_mov_b32 v23, 0" ::: "v23");
+    else if (NV > 8) asm volatile("v_mov_b32 v15, 0" ::: "v15");
+    else asm volatile("v_mov_b32 v7, 0" ::: "v7");
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(2);
+}
+template <int NV> __global__ void __launch_bounds__(512) hog2(unsigned long long ticks) {
+    if (NV >= 248) asm volatile("v_mov_b32 v247, 0" ::: "v247");
+    else asm volatile("v_mov_b32 v239, 0" ::: "v239");
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+// does a small-register kernel on another stream run BESIDE resident hog workgroups (done in microseconds) or after them?
+template <int HV, int SV>
+static int coreside(int ncu) {
+    hipStream_t cs, ws;
+    CK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&ws, hipStreamNonBlocking));
+    hipEvent_t e0, e1, h1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&h1));
+    hipLaunchKernelGGL(small<SV>, dim3(1024), dim3(256), 0, ws, 500ull);     // warm-up
+    CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(hog2<HV>, dim3(ncu), dim3(512), 0, cs, 100000ull);      // 1000 us on every CU
+    CK(hipEventRecord(h1, cs));
+    CK(hipEventRecord(e0, ws));
+    hipLaunchKernelGGL(small<SV>, dim3(1024), dim3(256), 0, ws, 500ull);     // 1024 workgroups x 5 us
+    CK(hipEventRecord(e1, ws));
+    CK(hipDeviceSynchronize());
+    float ms = 0, hm = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1)); CK(hipEventElapsedTime(&hm, e0, h1));
+    printf("{\"hog_vgprs\": %d, \"small_kernel_vgprs\": %d, \"small_kernel_done_after_ms\": %.4f, \"hogs_done_after_ms\": %.4f, \"ran_beside_the_hogs\": %s}\n", HV, SV, ms, hm,
+           ms < 0.6f * hm ? "true" : "false");
+    fflush(stdout);
+    return 0;
+}
 
 template <int NV>
 static float time_hogs(int blocks, unsigned long long ticks, hipStream_t s, int reps) {
@@ -111,5 +149,6 @@ int main(int argc, char** argv) {
     if (run_case<256>("512 threads x 256 VGPRs (the _tl twin)", ncu, ticks)) return 1;
     if (run_case<240>("512 threads x 240 VGPRs", ncu, ticks)) return 1;
     if (run_case<101>("512 threads x 101 VGPRs", ncu, ticks)) return 1;
+    if (coreside<248, 8>(ncu) || coreside<248, 16>(ncu) || coreside<248, 24>(ncu) || coreside<240, 16>(ncu) || coreside<240, 24>(ncu)) return 1;
     return 0;
 }

@@ -368,15 +368,31 @@ int yk_tcp_mesh_check(int rank, int nranks, const char* addr, int base_port, lon
 // wrong by construction (a reflecting boundary) -- this is a timing instrument, not a transport: it lets one GPU run the exact
 // launch / pack / copy / unpack / wait schedule of a rank of a decomposed job with an equally fast neighbour, so that what the
 // schedule hides of the exchange can be measured without a second GPU (tools/overlap_probe.py).
+// The copy is a kernel small enough in registers to run beside the marching workgroups (as a copy engine would: bandwidth, no CUs);
+// with YASK_MIRROR_LINK_GBPS=<g> in the environment the exchange also LASTS what its largest message would take on a link of g GB/s
+// (a rank's faces use different links at the same time), so that serial and overlapped schedules can be compared under a link.
+struct MirrorState { unsigned long long* t0 = nullptr; double gbps = 0; };
 int yk_env_init_mirror(yk_env_h e, int rank, int nranks) {
     try {
         if (!e) return 1;
         e->env->set_ranks(rank, nranks);
-        e->env->exch_start = [](void*, int n, const ykh::HaloMsg* m, void* stream) -> int {
-            for (int i = 0; i < n; i++) {
-                const size_t nb = std::min(m[i].send_bytes, m[i].recv_bytes);
-                if (nb && hipMemcpyAsync(m[i].recv_buf, m[i].send_buf, nb, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return 1;
+        MirrorState* ms = new MirrorState;
+        if (const char* g = getenv("YASK_MIRROR_LINK_GBPS")) ms->gbps = atof(g);
+        e->env->exch_start = [](void* u, int n, const ykh::HaloMsg* m, void* stream) -> int {
+            MirrorState* st = static_cast<MirrorState*>(u);
+            size_t most = 0;
+            if (st->gbps > 0 && !st->t0) {      // (first exchange under an emulated link: the start-time word, zeroed in stream order)
+                if (hipMalloc(&st->t0, sizeof(unsigned long long)) != hipSuccess) return 1;
+                if (hipMemsetAsync(st->t0, 0, sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess) return 1;
             }
+            try {
+                for (int i = 0; i < n; i++) {
+                    const size_t nb = std::min(m[i].send_bytes, m[i].recv_bytes);
+                    most = std::max(most, nb);
+                    ykh::launch_linear_copy(m[i].recv_buf, m[i].send_buf, nb, st->gbps > 0 ? st->t0 : nullptr, (hipStream_t)stream);
+                }
+                if (st->gbps > 0 && most) ykh::launch_hold_until(st->t0, (double)most / (st->gbps * 1.0e9), (hipStream_t)stream);
+            } catch (...) { return 1; }
             return 0;
         };
         e->env->exch_wait = [](void*, int, const ykh::HaloMsg*, void*) -> int { return 0; };
@@ -384,8 +400,11 @@ int yk_env_init_mirror(yk_env_h e, int rank, int nranks) {
         e->env->exch_reset = nullptr;
         e->env->exch_check = nullptr;
         if (e->env->user && e->env->user_free) e->env->user_free(e->env->user);
-        e->env->user = nullptr;
-        e->env->user_free = nullptr;
+        e->env->user = ms;
+        // (the 8-byte word is not given back: a synchronous hipMalloc / hipMemset / hipFree sequence per env left every LATER solution of
+        //  the process with slow cross-stream hand-offs -- small kernels 4x slower, 0.05-0.15 ms between dependent launches, measured
+        //  with this very instrument, gpurun_out/r3t vs r3w; cause not looked into, the instrument avoids it)
+        e->env->user_free = [](void* p) { delete static_cast<MirrorState*>(p); };
         return 0;
     } catch (...) { return 1; }
 }

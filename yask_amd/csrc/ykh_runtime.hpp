@@ -467,7 +467,8 @@ public:
     bool planned_split = true;
     bool shell_event_pending = false;  // ev_shell was recorded behind the shell part of the launch just issued
     hipEvent_t ev_shell = nullptr;
-    bool inline_pack = true;           // -[no-]hip_inline_pack: pack the halos between the two parts, on the compute stream (exchange_prepack)
+    bool inline_pack = false;          // -[no-]hip_inline_pack: pack the halos between the two parts, on the compute stream (exchange_prepack);
+                                       // off since the pack kernel fits in the 16 VGPRs a marching twin leaves and runs beside the second part
     bool prepacked_ = false;           // exchange_prepack() built and packed the messages of the exchange about to start
     void exchange_build_and_pack(hipStream_t st);
     void exchange_prepack(hipStream_t st);
@@ -595,6 +596,8 @@ struct HaloSeg {
     int lo[3], n[3];      // slab origin (local) and extent
 };
 void launch_halo_move(const std::vector<HaloSeg>& segs, bool pack, int elem_bytes, hipStream_t s);
+void launch_linear_copy(void* dst, const void* src, size_t bytes, unsigned long long* t0, hipStream_t st);
+void launch_hold_until(unsigned long long* t0, double seconds, hipStream_t st);
 void launch_box_gather(const BoxCopyArgs& a, hipStream_t s);    // var -> buf
 void launch_box_scatter(const BoxCopyArgs& a, hipStream_t s);   // buf -> var
 void launch_box_fill(const BoxCopyArgs& a, double v, hipStream_t s);

@@ -388,7 +388,8 @@ std::string Solution::get_command_line_help() const {
           " -[no-]hip_thin_slab_point_kernel  thin y/z exterior slabs run on the point kernel (default on)\n"
           " -[no-]hip_planned_split           planned launches go out as two launches with an event behind the shell's rounds (default on;\n"
           "                                   off: one launch, the exchange released by a device-side signal that a resident wave polls)\n"
-          " -[no-]hip_inline_pack             ... and the halos are packed between the two, on the compute stream (default on)\n"
+          " -[no-]hip_inline_pack             ... and the halos are packed between the two, on the compute stream (default off: the\n"
+          "                                   pack kernel runs beside the second launch on the communication stream)\n"
           " -[no-]hip_planned_launch          decomposed runs: the rank box as ONE launch of the marching kernel, shell blocks first,\n"
           "                                   the exchange released from the device when they are done (default on; off: exterior\n"
           "                                   slabs, then the interior in -hip_overlap_splits launches)\n"

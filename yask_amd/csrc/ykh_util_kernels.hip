@@ -232,35 +232,33 @@ __global__ void __launch_bounds__(256) bw_probe_k(const f4* __restrict__ a, cons
     if constexpr (KIND == 2) if (acc.x == 123.456f) d[0] = acc;
 }
 // ------------------------------------------------------------------ halo pack / unpack: all slabs of an exchange in one launch
+// Register budget: <= 16 VGPRs.  The marching twins that run a decomposed rank's launches use 242-248 VGPRs, which leaves 16 per lane of
+// every SIMD: a wave of a 16-VGPR kernel runs BESIDE a resident marching workgroup, one of 24 VGPRs waits until the launch is over
+// (tools/microbench/waiter_cost.hip: 1024 workgroups done after 0.024 ms vs after the hogs' 1.0 ms).  So: one segment per blockIdx.y
+// (no search, the segment's numbers are scalars), 32-bit indices inside a segment, byte strides prepared on the host.
 constexpr int HALO_SEGS = 40;
 struct HaloSegDev {
-    char* var_base; char* buf;
-    long long sx, sy, sz;            // var strides in ELEMENTS
-    int lo0, lo1, lo2;
-    unsigned n1, n2u;                // rows; units per row (n2 / vec)
-    unsigned vec;                    // elements per unit (1, or 16 / elem_bytes)
-    unsigned long long first;        // first unit of the segment in the launch's unit space
+    char* var0; char* buf;           // var address of the slab's first element; packed buffer of the segment
+    long long sxb, syb, sub;         // byte strides of a plane, a row, and a UNIT (vec elements) in the var
+    unsigned n1, n2u;                // rows per plane; units per row (n2 / vec)
+    unsigned units;                  // units in the segment
+    unsigned unit_bytes;             // 16, or the element size where a slab's rows cannot be moved as vectors
 };
-struct HaloMoveArgs { int nseg; unsigned long long total; int elem_bytes; HaloSegDev seg[HALO_SEGS]; };
+struct HaloMoveArgs { int nseg; HaloSegDev seg[HALO_SEGS]; };
 
 template <bool PACK>
 __global__ void __launch_bounds__(256) halo_move_k(const HaloMoveArgs a) {
-    for (unsigned long long u = (unsigned long long)blockIdx.x * 256 + threadIdx.x; u < a.total; u += (unsigned long long)gridDim.x * 256) {
-        int s = 0;
-        for (int k = 1; k < a.nseg; k++) s = (u >= a.seg[k].first) ? k : s;      // (cumulative starts are ascending)
-        const HaloSegDev& g = a.seg[s];
-        const unsigned long long r = u - g.first;
-        const unsigned kv = (unsigned)(r % g.n2u);
-        const unsigned long long rows = r / g.n2u;
-        const unsigned j = (unsigned)(rows % g.n1);
-        const long long i = (long long)(rows / g.n1);
-        const long long ve = (g.lo0 + i) * g.sx + (g.lo1 + (long long)j) * g.sy + (g.lo2 + (long long)kv * g.vec) * g.sz;     // var element
-        char* vp = g.var_base + ve * a.elem_bytes;
-        char* bp = g.buf + r * (unsigned long long)(g.vec * a.elem_bytes);
-        if (g.vec * a.elem_bytes == 16) {
+    const HaloSegDev& g = a.seg[blockIdx.y];
+    const unsigned n2u = g.n2u, n1 = g.n1, units = g.units, ub = g.unit_bytes;
+    for (unsigned r = blockIdx.x * 256u + threadIdx.x; r < units; r += gridDim.x * 256u) {
+        const unsigned rows = r / n2u, kv = r - rows * n2u;
+        const unsigned i = rows / n1, j = rows - i * n1;
+        char* vp = g.var0 + ((long long)i * g.sxb + (long long)j * g.syb + (long long)kv * g.sub);
+        char* bp = g.buf + (unsigned long long)r * ub;
+        if (ub == 16) {
             if (PACK) *reinterpret_cast<uint4*>(bp) = *reinterpret_cast<const uint4*>(vp);
             else *reinterpret_cast<uint4*>(vp) = *reinterpret_cast<const uint4*>(bp);
-        } else if (a.elem_bytes == 4) {
+        } else if (ub == 4) {
             if (PACK) *reinterpret_cast<unsigned*>(bp) = *reinterpret_cast<const unsigned*>(vp);
             else *reinterpret_cast<unsigned*>(vp) = *reinterpret_cast<const unsigned*>(bp);
         } else {
@@ -276,31 +274,65 @@ void launch_halo_move(const std::vector<HaloSeg>& segs, bool pack, int elem_byte
     size_t k = 0;
     while (k < segs.size()) {
         HaloMoveArgs a;
-        a.nseg = 0; a.total = 0; a.elem_bytes = elem_bytes;
+        a.nseg = 0;
+        unsigned long long most = 0;
         for (; k < segs.size() && a.nseg < HALO_SEGS; k++) {
             const HaloSeg& h = segs[k];
             if (h.n[0] <= 0 || h.n[1] <= 0 || h.n[2] <= 0) continue;
             HaloSegDev& d = a.seg[a.nseg];
-            d.var_base = (char*)h.var_base; d.buf = (char*)h.buf;
-            d.sx = h.sx; d.sy = h.sy; d.sz = h.sz;
-            d.lo0 = h.lo[0]; d.lo1 = h.lo[1]; d.lo2 = h.lo[2];
             // 16-byte units where every row of the slab starts and ends on a vector boundary on both sides
             const bool vec_ok = h.sz == 1 && h.n[2] % (int)V == 0 && (((long long)h.lo[2]) % (long long)V + V) % V == 0 &&
                                 h.sy % V == 0 && h.sx % V == 0 && ((uintptr_t)h.var_base % 16) == 0 && ((uintptr_t)h.buf % 16) == 0;
-            d.vec = vec_ok ? V : 1;
+            const unsigned vec = vec_ok ? V : 1;
+            d.var0 = (char*)h.var_base + ((long long)h.lo[0] * h.sx + (long long)h.lo[1] * h.sy + (long long)h.lo[2] * h.sz) * elem_bytes;
+            d.buf = (char*)h.buf;
+            d.sxb = h.sx * elem_bytes; d.syb = h.sy * elem_bytes; d.sub = h.sz * (long long)vec * elem_bytes;
             d.n1 = (unsigned)h.n[1];
-            d.n2u = (unsigned)h.n[2] / d.vec;
-            d.first = a.total;
-            a.total += (unsigned long long)h.n[0] * d.n1 * d.n2u;
+            d.n2u = (unsigned)h.n[2] / vec;
+            const unsigned long long units = (unsigned long long)h.n[0] * d.n1 * d.n2u;
+            if (units >= (1ull << 32)) YKH_THROW("halo pack: a slab of more than 2^32 units");
+            d.units = (unsigned)units;
+            d.unit_bytes = vec * (unsigned)elem_bytes;
+            most = std::max(most, units);
             a.nseg++;
         }
-        if (a.nseg == 0 || a.total == 0) continue;
-        const unsigned long long want = (a.total + 255) / 256;
-        const unsigned blocks = (unsigned)std::min<unsigned long long>(want, 16384);       // (grid-strided beyond that)
-        if (pack) hipLaunchKernelGGL(halo_move_k<true>, dim3(blocks), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(halo_move_k<false>, dim3(blocks), dim3(256), 0, st, a);
+        if (a.nseg == 0 || most == 0) continue;
+        const unsigned bx = (unsigned)std::min<unsigned long long>((most + 255) / 256, 4096);       // (grid-strided beyond that)
+        if (pack) hipLaunchKernelGGL(halo_move_k<true>, dim3(bx, (unsigned)a.nseg), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(halo_move_k<false>, dim3(bx, (unsigned)a.nseg), dim3(256), 0, st, a);
         YKH_HIP(hipGetLastError());
     }
+}
+
+// ------------------------------------------------------------------ the mirror transport's stand-in for a copy engine + a link
+// linear_copy_k: a device-to-device copy in <= 16 VGPRs, so that (like an SDMA engine, unlike the runtime's blit kernels) it runs
+// BESIDE resident marching workgroups and takes bandwidth, not CUs.  hold_until_k: one wave that ends `ticks` (100 MHz) after the
+// first copy of the exchange started -- the exchange then lasts what a link of the given speed would take for its largest message
+// (a rank's faces travel on different links at the same time).  Instrument only (yk_env_init_mirror, tools/overlap_probe.py).
+__global__ void __launch_bounds__(256) linear_copy_k(uint4* d, const uint4* s, unsigned n16, unsigned* d4, const unsigned* s4, unsigned n4, unsigned long long* t0) {
+    if (t0 && blockIdx.x == 0 && threadIdx.x == 0) (void)atomicCAS(t0, 0ull, (unsigned long long)wall_clock64());
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) d[i] = s[i];
+    if (blockIdx.x == 0 && threadIdx.x < n4) d4[threadIdx.x] = s4[threadIdx.x];      // (a tail of < 16 bytes, in 4-byte words)
+}
+__global__ void __launch_bounds__(64) hold_until_k(unsigned long long* t0, unsigned long long ticks) {
+    if (threadIdx.x == 0) {
+        const unsigned long long start = __hip_atomic_load(t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (start) while ((unsigned long long)wall_clock64() - start < ticks) __builtin_amdgcn_s_sleep(16);
+        __hip_atomic_store(t0, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+void launch_linear_copy(void* dst, const void* src, size_t bytes, unsigned long long* t0, hipStream_t st) {
+    if (!bytes) return;
+    if (bytes % 4 || ((uintptr_t)dst | (uintptr_t)src) % 16 || bytes >= (1ull << 35)) YKH_THROW("linear copy: unaligned or oversized message");
+    const unsigned n16 = (unsigned)(bytes / 16), n4 = (unsigned)((bytes % 16) / 4);
+    const unsigned blocks = std::max(1u, std::min((n16 + 255u) / 256u, 2048u));
+    hipLaunchKernelGGL(linear_copy_k, dim3(blocks), dim3(256), 0, st, (uint4*)dst, (const uint4*)src, n16, (unsigned*)((char*)dst + (size_t)n16 * 16),
+                       (const unsigned*)((const char*)src + (size_t)n16 * 16), n4, t0);
+    YKH_HIP(hipGetLastError());
+}
+void launch_hold_until(unsigned long long* t0, double seconds, hipStream_t st) {
+    hipLaunchKernelGGL(hold_until_k, dim3(1), dim3(64), 0, st, t0, (unsigned long long)(std::max(0.0, seconds) * 1.0e8));
+    YKH_HIP(hipGetLastError());
 }
 
 // ------------------------------------------------------------------ stream-ordered waits on words in device memory
