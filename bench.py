@@ -297,7 +297,7 @@ def main():
                     help="N>1: halo transport.  ipc: device-to-device copies through HIP IPC handles + stream-ordered flags; rccl: grouped "
                          "ncclSend/ncclRecv; torch: torch.distributed P2P (host-staged with gloo: tests).  auto (default): ipc and rccl each "
                          "run a few steps during warm-up, the faster one is used and both timings are reported")
-    ap.add_argument("--schedule", default="auto", choices=["auto", "planned", "planned35", "planned_inlinepack", "slabs", "serial"],
+    ap.add_argument("--schedule", default="auto", choices=["auto", "planned", "planned35", "planned_inlinepack", "halves", "slabs", "serial"],
                     help="N>1: how a step is issued.  planned / planned35: the rank box as ONE launch of equal blocks, shell blocks first (done "
                          "after 55 / 35 %% of the launch), the halo exchange released from the device when they are done; slabs: "
                          "exterior slabs, then the exchange beside the interior (round 2); serial: the whole box, "
@@ -438,10 +438,15 @@ def main():
     # "planned" / "planned35": the rank box as ONE launch of equal blocks in rounds, shell blocks first, the exchange released from the
     # device when they are done (round 3; the shell is to be done after 55 / 35 % of the launch: earlier = more rounds = more chunk
     # prologues); "slabs": round 2's exterior slabs, then the interior; "serial": the whole box, then the exchange
-    SCHEDULES = {"planned": "-overlap_comms -hip_planned_launch -hip_shell_pct 55 -no-hip_inline_pack", "planned35": "-overlap_comms -hip_planned_launch -hip_shell_pct 35 -no-hip_inline_pack",
+    # "halves" (late round 3): two launches in regular order -- the outer and the inner half of the x range -- each followed by the
+    # exchange of its own part of the faces, which travels while the other half is computed (no shell-first order; where a rank's box
+    # does not allow it the library falls back to "planned")
+    SCHEDULES = {"planned": "-overlap_comms -hip_planned_launch -no-hip_halves -hip_shell_pct 55 -no-hip_inline_pack",
+                 "planned35": "-overlap_comms -hip_planned_launch -no-hip_halves -hip_shell_pct 35 -no-hip_inline_pack",
                  # (the halos packed between the two parts of the launch, on the compute stream, instead of beside the second part)
-                 "planned_inlinepack": "-overlap_comms -hip_planned_launch -hip_shell_pct 55 -hip_inline_pack",
-                 "slabs": "-overlap_comms -no-hip_planned_launch -hip_overlap_splits 1", "serial": "-no-overlap_comms"}
+                 "planned_inlinepack": "-overlap_comms -hip_planned_launch -no-hip_halves -hip_shell_pct 55 -hip_inline_pack",
+                 "halves": "-overlap_comms -hip_planned_launch -hip_halves -hip_shell_pct 55 -no-hip_inline_pack",
+                 "slabs": "-overlap_comms -no-hip_planned_launch -no-hip_halves -hip_overlap_splits 1", "serial": "-no-overlap_comms -no-hip_halves"}
     schedule, schedule_ms = None, None
     t = 0
     if world > 1:

@@ -145,10 +145,23 @@ int yk_plan_wavefront(yk_idx_t lo, yk_idx_t hi, yk_idx_t width, yk_idx_t angle, 
  * done after shell_pct % of the launch), then the interior in pieces sized against the simulated CU time line.  flags bit 0 =
  * the block is part of the shell (it counts towards the signal that releases the exchange).  Writes <= cap descriptors, returns
  * their number; info[0..4] = shell blocks, simulated end of the shell, simulated end of the launch, the undivided box simulated
- * the same way (plane-iterations), interior mode used (1 greedy budgets, 2 uniform chunks).  No GPU needed. */
+ * the same way (plane-iterations), mode used (3 rounds of equal blocks -- modes 0 and 3 --, 1 greedy budgets, 2 uniform chunks,
+ * 4 halves).  No GPU needed. */
 typedef struct { int x0, x1, y0, y1, z0, z1, flags, start; } yk_block_desc_t;
 int yk_plan_blocks(const yk_idx_t* n3, const int* has_lo3, const int* has_hi3, const yk_idx_t* width3, int tile_y, int tile_z,
                    int overhead, int num_cus, int shell_pct, int mode, yk_block_desc_t* out, int cap, yk_idx_t* info5);
+
+/* Pipelined half-exchanges (`-hip_halves`).  The reference progresses its halo messages while it computes
+ * (adv_halo_exchange, src/kernel/lib/halo.cpp:494-574, called per micro-block, context.cpp:1037-1040); here a step of a decomposed
+ * rank is TWO launches in regular order -- the outer x-half [0, q1) u [q2, nx) and the inner half [q1, q2) -- and each is followed
+ * by the exchange of its own part of the faces, which travels while the other half is computed.  yk_plan_blocks(mode = 4) returns
+ * the two launches' blocks (info5[0] = blocks of the first launch; no block signals);
+ *   yk_plan_halves      the cut planes q1, q2 for a box of nx planes whose x neighbours need `xwidth` planes; returns 1, or 0
+ *                       when the box is too short;
+ *   yk_plan_halves_slab the x-ranges (first, size pairs in out4; returns their number, 0..2) of a halo slab [lo, lo + n) that
+ *                       travel with half `half`; slabs of neighbours offset in x travel whole with half 0.   No GPU needed. */
+int yk_plan_halves(yk_idx_t nx, yk_idx_t xwidth, yk_idx_t* q1, yk_idx_t* q2);
+int yk_plan_halves_slab(int half, int x_neighbor, yk_idx_t lo, yk_idx_t n, yk_idx_t q1, yk_idx_t q2, yk_idx_t* out4);
 
 /* ---- solution: replaces yk_solution, include/aux/yk_solution_api.hpp:82-1292 ---- */
 const char* yk_solution_get_name(yk_soln_h s);                               /* :90 */

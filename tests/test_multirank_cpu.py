@@ -419,3 +419,81 @@ def test_block_plans_of_the_baseline_blocks_stay_close_to_the_undivided_sweep():
         print(n, "blocks", len(blocks), "shell blocks", n_sig, "shell done", shell_done, "end", makespan, "undivided", undivided, "mode", mode)
         assert makespan <= bound * undivided, (n, makespan, undivided)
         assert shell_done <= 0.75 * makespan          # the exchange gets at least a quarter of the launch to hide in
+
+
+# ------------------------------------------------------------------ (g) pipelined half-exchanges: the two launches and the cut faces
+@pytest.mark.parametrize("n,ty,tz,ncu", [((64, 44, 72), 16, 32, 24), ((512, 512, 512), 32, 128, 256), ((1024, 1024, 512), 32, 128, 256),
+                                         ((130, 30, 50), 8, 16, 7), ((512, 512, 512), 16, 128, 256), ((37, 17, 129), 32, 128, 256)])
+def test_halves_plan_is_the_regular_tiling_in_two_launches(n, ty, tz, ncu):
+    """Plan mode 4 (Solution::run_stage_halves, -hip_halves): every point of the rank box exactly once, whole tiles of the regular
+    tiling, the first `cut` blocks cover exactly the outer x-half [0, q1) u [q2, nx), the rest the inner half; no block signals
+    (nothing is special: the exchange of a half starts when its launch has ended); q1, q2 come from the x extent alone."""
+    q1, q2 = _capi.idx_t(), _capi.idx_t()
+    assert _lib().yk_plan_halves(n[0], 8, C.byref(q1), C.byref(q2)) == 1
+    q1, q2 = q1.value, q2.value
+    assert 8 <= q1 == n[0] // 4 and q2 == n[0] - q1
+    blocks, info = _plan(n, (0, 1, 0), (1, 1, 1), ty=ty, tz=tz, overhead=9, ncu=ncu, mode=4)
+    cut, mode = info[0], info[4]
+    assert mode == 4 and 0 < cut < len(blocks)
+    count = np.zeros(n, np.int32)
+    for i, (x0, x1, y0, y1, z0, z1, flags, start) in enumerate(blocks):
+        assert 0 <= x0 < x1 <= n[0] and flags == 0
+        assert y0 % ty == 0 and z0 % tz == 0 and y1 == min(y0 + ty, n[1]) and z1 == min(z0 + tz, n[2])
+        outer = x1 <= q1 or x0 >= q2
+        inner = x0 >= q1 and x1 <= q2
+        assert (outer if i < cut else inner), (i, cut, x0, x1, q1, q2)
+        count[x0:x1, y0:y1, z0:z1] += 1
+    assert (count == 1).all()
+    # all blocks of a launch have (nearly) the same length: they start and end together
+    for part in (blocks[:cut], blocks[cut:]):
+        lens = [b[1] - b[0] for b in part]
+        assert max(lens) - min(lens) <= 1
+
+
+def test_halves_plans_of_the_baseline_blocks_cost_what_the_undivided_sweep_costs():
+    """Cost model: the two launches of the halves schedule against the same box as one regular launch (plane-iterations, 256 CUs,
+    iso3dfd's tile and 9 plane-iterations of prologue).  The shell-first plans of mode 0 measured 1.05-1.13x on the GPU; the same
+    blocks in regular order 1.01-1.02x -- which is what these launches are."""
+    for n, ty in (((512, 512, 512), 32), ((1024, 1024, 512), 32), ((512, 512, 1024), 32), ((512, 512, 512), 16)):
+        blocks, info = _plan(n, (0, 0, 0), (1, 1, 1), ty=ty, mode=4)
+        cut, half_a, makespan, undivided, mode = info
+        print(n, "tile y", ty, "blocks", len(blocks), "first launch", cut, "ends at", half_a, "both", makespan, "undivided", undivided)
+        assert makespan <= 1.08 * undivided
+        assert 0.4 * makespan <= half_a <= 0.6 * makespan       # two halves: each transfer has the other launch to hide behind
+        assert cut % 256 == 0 and (len(blocks) - cut) % 256 == 0  # whole rounds of workgroups in both launches
+
+
+def test_halves_cut_a_face_at_the_same_planes_on_both_sides_and_x_faces_travel_first():
+    def ranges(half, xnb, lo, n, q1, q2):
+        out = (_capi.idx_t * 4)()
+        k = _lib().yk_plan_halves_slab(half, xnb, lo, n, q1, q2, out)
+        return [(out[2 * i], out[2 * i + 1]) for i in range(k)]
+    nx, q1, q2 = 512, 128, 384
+    # a y / z face: whole x extent; the two halves partition it
+    assert ranges(0, 0, 0, nx, q1, q2) == [(0, 128), (384, 128)]
+    assert ranges(1, 0, 0, nx, q1, q2) == [(128, 256)]
+    # ... also when the slab reaches into the rank's own x halo at a global boundary (vars read diagonally: ssg's mu)
+    assert ranges(0, 0, -1, nx + 2, q1, q2) == [(-1, 129), (384, 129)]
+    assert ranges(1, 0, -1, nx + 2, q1, q2) == [(128, 256)]
+    # x faces (and edges / corners that are offset in x) travel whole with the outer half
+    assert ranges(0, 1, 0, 8, q1, q2) == [(0, 8)] and ranges(1, 1, 0, 8, q1, q2) == []
+    assert ranges(0, 1, nx - 8, 8, q1, q2) == [(nx - 8, 8)] and ranges(1, 1, nx - 8, 8, q1, q2) == []
+    # a var without the x dim (extent 1 at x = 0): once, with the outer half
+    assert ranges(0, 0, 0, 1, q1, q2) == [(0, 1)] and ranges(1, 0, 0, 1, q1, q2) == []
+    # every plane of a slab is in exactly one range of exactly one half
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        nx = int(rng.integers(32, 700))
+        a, b = _capi.idx_t(), _capi.idx_t()
+        assert _lib().yk_plan_halves(nx, 8, C.byref(a), C.byref(b)) == 1
+        lo = int(rng.integers(-4, 1)); n = nx - lo + int(rng.integers(0, 5))
+        seen = np.zeros(n, np.int32)
+        for h in (0, 1):
+            for l, m in ranges(h, 0, lo, n, a.value, b.value):
+                assert m > 0
+                seen[l - lo:l - lo + m] += 1
+        assert (seen == 1).all()
+    # too short in x for an outer quarter that holds the x halo: no halves
+    a, b = _capi.idx_t(), _capi.idx_t()
+    assert _lib().yk_plan_halves(24, 8, C.byref(a), C.byref(b)) == 0
+    assert _lib().yk_plan_halves(32, 8, C.byref(a), C.byref(b)) == 1 and (a.value, b.value) == (8, 24)

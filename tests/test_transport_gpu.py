@@ -264,6 +264,36 @@ def test_eight_ranks_on_the_compact_2x2x2_grid(gpu, stencil, g, steps, sched, mo
         assert np.abs(full[n].astype(np.float64) - r).max() / max(1.0 if stencil == "iso3dfd" else 1e-30, np.abs(r).max()) <= 2e-5, n
 
 
+@pytest.mark.parametrize("stencil,g,world,nr,steps,transport", [("iso3dfd", (64, 40, 72), 8, (2, 2, 2), 4, "ipc"), ("ssg", (64, 28, 40), 8, (2, 2, 2), 3, "ipc"),
+                                                               ("iso3dfd", (40, 48, 40), 4, (1, 2, 2), 3, "tcp"), ("iso3dfd", (72, 40, 72), 2, (1, 1, 2), 5, "ipc")])
+def test_pipelined_half_exchanges_equal_one_rank(gpu, stencil, g, world, nr, steps, transport, monkeypatch):
+    """-hip_halves: a stage of a decomposed rank is two launches in regular order -- the outer x-half [0, nx/4) u [3nx/4, nx), then
+    the inner half -- and each is followed by the exchange of ITS part of the faces, finished only after the other half has been
+    launched (the reference progresses its messages while it computes: adv_halo_exchange, src/kernel/lib/halo.cpp:494-574).  Same
+    kernels, same per-point arithmetic, halos in place before the launch that reads them: the assembled result equals the one-rank
+    run bit for bit -- 2x2x2 (x faces in place with the outer half, y / z faces cut in x), grids without x neighbours, two
+    stages with in-place fields (ssg), odd and even step counts, the device-to-device and the host-staged transport."""
+    monkeypatch.setenv("YASK_TEST_TRANSPORT", transport)
+    monkeypatch.setenv("YASK_TEST_EXTRA_OPTS", "-hip_halves")
+    parts = _run_ranks(world, "run", stencil=stencil, g=g, nr=nr, steps=steps)
+    full = _assemble(parts, stencil, g)
+    one = _one_rank(stencil, g, steps)
+    for n in FIELDS[stencil]:
+        assert np.array_equal(full[n], one[n]), n
+    # the schedule really ran (a box too short in x falls back to planned launches): per step and stage every y / z face neighbour
+    # gets TWO messages, an x neighbour one (every rank of these grids is a corner: one neighbour per decomposed dim)
+    nx_nb = 1 if nr[0] > 1 else 0
+    nyz_nb = sum(1 for d in (1, 2) if nr[d] > 1)
+    for _, _, _, st in parts:
+        assert st["grid"] == list(nr)
+        if stencil == "iso3dfd":
+            # (run_solution() first exchanges both step slots of p: in-place x faces are one message per slot)
+            assert st["msgs"] == 2 * nx_nb + nyz_nb + steps * (nx_nb + 2 * nyz_nb), st["msgs"]
+        else:
+            assert st["msgs"] >= 2 * steps * (nx_nb + 2 * nyz_nb), st["msgs"]
+        assert st["wait"] >= 0 and st["ext"] > 0 and st["xfer"] > 0 and st["hidden"] is not None
+
+
 @pytest.mark.parametrize("transport", ["tcp", "ipc"])
 @pytest.mark.parametrize("nr,g", [((4, 1, 1), (64, 24, 40)), ((2, 2, 1), (40, 48, 40)), ((1, 2, 2), (24, 40, 72))])
 def test_four_ranks_slab_and_pencil_grids(gpu, nr, g, transport, monkeypatch):

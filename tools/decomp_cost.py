@@ -27,6 +27,8 @@ SSG_CASES = [
     ("ssg 1024^3 global / 8 GPUs, 2x2x2, local 512^3", (512, 512, 512), (0, 0, 0), (1, 1, 1)),
 ]
 CONFIGS = [  # label, options
+    # round 3, late: the pipelined half-exchange schedule -- outer x-half, inner x-half, regular order (shell_ms = the outer half)
+    ("halves: two launches in regular order (-hip_halves)", "-hip_planned_launch -hip_halves"),
     ("planned rounds pct55 (default)", "-hip_planned_launch -hip_shell_pct 55 -hip_plan_mode 0"),
     ("planned rounds pct35", "-hip_planned_launch -hip_shell_pct 35 -hip_plan_mode 0"),
     ("planned, one round if shortest (pct100: descriptors + signals, no early shell)", "-hip_planned_launch -hip_shell_pct 100 -hip_plan_mode 0"),
@@ -45,6 +47,8 @@ def main():
     ap.add_argument("--stencil", default="iso3dfd")
     ap.add_argument("--quick", action="store_true", help="the two BASELINE blocks, three configurations")
     ap.add_argument("--reps", type=int, default=8)
+    ap.add_argument("--configs", default="", help="only the configurations whose label contains this text (comma-separated alternatives)")
+    ap.add_argument("--cases", type=int, default=99, help="only the first N cases")
     args = ap.parse_args()
     from yask_amd import yk_factory
     from yask_amd.kernel import yk_env
@@ -53,7 +57,10 @@ def main():
     cases = SSG_CASES if args.stencil == "ssg" else CASES
     configs = CONFIGS
     if args.quick:
-        cases, configs = cases[:2], [CONFIGS[0], CONFIGS[2], CONFIGS[3], CONFIGS[7], CONFIGS[8]]
+        cases, configs = cases[:2], [CONFIGS[0], CONFIGS[1], CONFIGS[3], CONFIGS[4], CONFIGS[8], CONFIGS[9]]
+    if args.configs:
+        configs = [c for c in configs if any(k in c[0] for k in args.configs.split(","))]
+    cases = cases[:args.cases]
     out = []
     ramped = False
     for name, size, lo, hi in cases:

@@ -23,7 +23,8 @@ CASES = {  # name -> (global size, rank grid, rank played)
     "ssg": [("ssg 1024^3 / 8 GPUs 2x2x2: 512^3 block", (1024, 1024, 1024), (2, 2, 2), 0),
             ("ssg 512^3 / 8 GPUs 2x2x2: 256^3 block", (512, 512, 512), (2, 2, 2), 0)],
 }
-SCHEDULES = [("planned (rounds, shell first)", "-overlap_comms -hip_planned_launch"),
+SCHEDULES = [("halves: two launches in regular order, half-exchanges pipelined (-hip_halves)", "-overlap_comms -hip_planned_launch -hip_halves"),
+             ("planned (rounds, shell first)", "-overlap_comms -hip_planned_launch"),
              ("planned, pack in line on the compute stream (-hip_inline_pack)", "-overlap_comms -hip_planned_launch -hip_inline_pack"),
              ("planned, one launch + device-side signal (-no-hip_planned_split)", "-overlap_comms -hip_planned_launch -no-hip_planned_split"),
              ("planned, shell by 35 %", "-overlap_comms -hip_planned_launch -hip_shell_pct 35"),

@@ -85,6 +85,8 @@ PROTOTYPES = {
     "yk_plan_rank": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(RankPlan)]),
     "yk_plan_blocks": (C.c_int, [C.POINTER(idx_t), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(idx_t), C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.POINTER(BlockDesc), C.c_int, C.POINTER(idx_t)]),
+    "yk_plan_halves": (C.c_int, [idx_t, idx_t, C.POINTER(idx_t), C.POINTER(idx_t)]),
+    "yk_plan_halves_slab": (C.c_int, [C.c_int, C.c_int, idx_t, idx_t, idx_t, idx_t, C.POINTER(idx_t)]),
     "yk_plan_halo_slab": (C.c_int, [C.c_int, C.POINTER(RankPlan), C.POINTER(C.c_int), C.POINTER(idx_t), C.POINTER(idx_t),
                                     C.c_int, C.c_int, C.POINTER(Box)]),
     "yk_last_error": (_S, []),

@@ -537,8 +537,26 @@ int yk_plan_blocks(const yk_idx_t* n3, const int* has_lo3, const int* has_hi3, c
     try { p = plan_blocks(in); } catch (const PlanError& e) { YKH_THROW(e.what()); }
     static_assert(sizeof(yk_block_desc_t) == sizeof(BlockDesc), "yk_block_desc_t mirrors ykh::BlockDesc");
     for (int i = 0; i < (int)p.blocks.size() && i < cap && out; i++) std::memcpy(&out[i], &p.blocks[i], sizeof(BlockDesc));
-    if (info5) { info5[0] = p.n_signal; info5[1] = p.shell_done; info5[2] = p.makespan; info5[3] = p.undivided; info5[4] = p.mode_used; }
+    if (info5) { info5[0] = p.mode_used == 4 ? p.cut : p.n_signal; info5[1] = p.shell_done; info5[2] = p.makespan; info5[3] = p.undivided; info5[4] = p.mode_used; }
     return (int)p.blocks.size();
+    YK_CATCH(-1)
+}
+int yk_plan_halves(yk_idx_t nx, yk_idx_t xwidth, yk_idx_t* q1, yk_idx_t* q2) {
+    YK_TRY
+    if (!q1 || !q2) YKH_THROW("yk_plan_halves: null argument");
+    idx_t a = 0, b = 0;
+    const bool ok = halves_split(nx, xwidth, &a, &b);
+    *q1 = a; *q2 = b;
+    return ok ? 1 : 0;
+    YK_CATCH(-1)
+}
+int yk_plan_halves_slab(int half, int x_neighbor, yk_idx_t lo, yk_idx_t n, yk_idx_t q1, yk_idx_t q2, yk_idx_t* out4) {
+    YK_TRY
+    if (!out4 || half < 0 || half > 1) YKH_THROW("yk_plan_halves_slab: bad argument");
+    idx_t l[2] = {0, 0}, m[2] = {0, 0};
+    const int k = halves_slab_ranges(half, x_neighbor != 0, lo, n, q1, q2, l, m);
+    for (int i = 0; i < 2; i++) { out4[2 * i] = l[i]; out4[2 * i + 1] = m[i]; }
+    return k;
     YK_CATCH(-1)
 }
 

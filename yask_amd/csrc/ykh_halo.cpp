@@ -57,6 +57,26 @@ void Solution::alloc_halo_buffers() {
         }
         x->send_cap = sb * elem_bytes();
         x->recv_cap = rb * elem_bytes();
+        // the same slabs cut at the planes of the two x-halves (pipelined half-exchanges, Solution::run_stage_halves): both ends of a
+        // link cut at the same planes (q1, q2 depend on the x extent alone, which y / z neighbours share)
+        idx_t q1 = 0, q2 = 0;
+        if (halves_geometry(&q1, &q2))
+            for (int dirn = 0; dirn < 2; dirn++) {
+                const std::vector<Slab>& whole = dirn ? x->recv : x->send;
+                for (int h = 0; h < 2; h++) {
+                    std::vector<Slab>& part = dirn ? x->recv_h[h] : x->send_h[h];
+                    for (const Slab& sl : whole) {
+                        idx_t l[2], m[2];
+                        const int k = halves_slab_ranges(h, nb.ofs[0] != 0, sl.lo[0], sl.n[0], q1, q2, l, m);
+                        for (int i = 0; i < k; i++) {
+                            Slab c = sl;
+                            c.lo[0] = l[i]; c.n[0] = m[i];
+                            c.elems = c.n[0] * c.n[1] * c.n[2] * vars[sl.var]->misc_elems;
+                            part.push_back(c);
+                        }
+                    }
+                }
+            }
         // in-place transfer? (decided from geometry only, so both ends of a link agree)
         x->direct = direct_halo && !wf_multi() && ndd == 3 && nb.ofs[0] != 0 && nb.ofs[1] == 0 && nb.ofs[2] == 0 &&
                     x->send.size() == x->recv.size() && !x->send.empty();
@@ -121,10 +141,12 @@ static size_t collect_slabs(Solution& s, const std::vector<Slab>& slabs, void* b
 void Solution::exchange_build_and_pack(hipStream_t st) {
     std::vector<HaloMsg>& msgs = pending_msgs;
     std::vector<HaloSeg> segs;
+    const int half = exch_half_;          // -1: whole faces; 0 / 1: the slabs of one x-half (pipelined half-exchanges)
     for (auto& x : xfers) {
         if (x->direct) {
             // one message per dirty (var, slot): whole planes (with their y/z pads) straight from / into the var
             x->send_now = x->recv_now = 0;
+            if (half == 1) continue;      // (x faces travel with the outer half)
             for (size_t i = 0; i < x->send.size(); i++) {
                 const Slab &ss = x->send[i], &rs = x->recv[i];
                 Var& v = *vars[ss.var];
@@ -145,10 +167,10 @@ void Solution::exchange_build_and_pack(hipStream_t st) {
             }
             continue;
         }
-        x->send_now = collect_slabs(*this, x->send, x->send_buf, segs);
+        x->send_now = collect_slabs(*this, half < 0 ? x->send : x->send_h[half], x->send_buf, segs);
         // receive size: same rule evaluated on my recv slabs (neighbour's dirty flags mirror mine)
         size_t r = 0;
-        for (const Slab& sl : x->recv) {
+        for (const Slab& sl : (half < 0 ? x->recv : x->recv_h[half])) {
             Var& v = *vars[sl.var];
             for (int slot = 0; slot < v.nslots; slot++)
                 if (v.dirty[slot]) r += (size_t)sl.elems * elem_bytes();
@@ -240,12 +262,14 @@ void Solution::exchange_halos(idx_t /*t_written*/, int /*stage*/, bool start_onl
         phase_mark(PH_XFER1, comm_stream);
         std::vector<HaloSeg> segs;
         for (auto& x : xfers)
-            if (x->recv_now && !x->direct) collect_slabs(*this, x->recv, x->recv_buf, segs);
+            if (x->recv_now && !x->direct) collect_slabs(*this, exch_half_ < 0 ? x->recv : x->recv_h[exch_half_], x->recv_buf, segs);
         launch_halo_move(segs, /*pack=*/false, elem_bytes(), comm_stream);
         phase_mark(PH_UNPACK1, comm_stream);
         YKH_HIP(hipEventRecord(ev_b, comm_stream));
         YKH_HIP(hipStreamWaitEvent(compute_stream, ev_b, 0));
-        for (auto& v : vars) v->set_dirty_all(false);
+        // (the outer half's exchange leaves the flags up: the inner half's part of the same faces has yet to travel)
+        if (exch_half_ != 0)
+            for (auto& v : vars) v->set_dirty_all(false);
         msgs.clear();
     }
 }
@@ -256,6 +280,7 @@ void Solution::exchange_halos_all() {
     // one did not.  Every rank must post the same messages, so everything counts as possibly dirty -- the
     // reference's set_all_neighbor_vars_dirty() (context.cpp:234, halo.cpp:84-161 keeps self/others flags).
     for (auto& v : vars) v->before_device_use();      // raw buffers handed out: the caller may have written through them
+    exch_half_ = -1;                                   // whole faces
     if (env->nranks > 1)
         for (auto& v : vars) v->set_dirty_all(true);
     exchange_halos(0, 0, true, false);

@@ -56,7 +56,9 @@ struct BlockPlanIn {
     double shell_frac = 0.45;                             // aim: the shell is done after this fraction of the launch
     int mode = 0;                                         // 0: rounds -- every tile cut at the same planes, equal blocks, shell blocks first
                                                           // (default); 1: thin x slabs + shell chunks + greedy per-CU budgets; 2: the same
-                                                          // with uniform interior chunks (the first planner: measured 1.3-1.6x, kept for A/B)
+                                                          // with uniform interior chunks (the first planner: measured 1.3-1.6x, kept for A/B);
+                                                          // 3: the blocks of 0 in regular-launch order (diagnostic); 4: the two x-halves of the
+                                                          // pipelined half-exchange schedule (plan_halves below; NOT a shell-first plan)
     idx_t min_len = 16;                                   // no block shorter than this (unless its whole range is)
 };
 struct BlockPlan {
@@ -64,8 +66,18 @@ struct BlockPlan {
     idx_t n_signal = 0;
     idx_t makespan = 0, shell_done = 0;  // simulated, in plane-iterations
     idx_t undivided = 0;                 // the same box as ONE regular launch (tiles x best uniform chunks), simulated the same way
-    int mode_used = 0;                   // 3 rounds, 1 greedy, 2 uniform
+    int mode_used = 0;                   // 3 rounds, 1 greedy, 2 uniform, 4 halves
+    idx_t cut = 0;                       // mode 4: blocks [0, cut) are half A (the first launch), [cut, size) half B
 };
 BlockPlan plan_blocks(const BlockPlanIn& in);
+
+// ---- pipelined half-exchanges (Solution::run, -hip_halves): the rank box is cut at x = q1 and x = q2 into an OUTER half
+// A = [0, q1) u [q2, nx) and an INNER half B = [q1, q2); both are functions of nx alone, so that ranks that are y / z
+// neighbours of each other (same x index, hence the same nx) cut their faces at the same planes.
+//   halves_split       false when the box is too short in x for it (q1 must hold the x halo a neighbour needs)
+//   halves_slab_ranges the part of a halo slab's x extent [lo, lo + n) that travels with half h: up to two ranges; slabs of a
+//                      neighbour that is offset in x (x faces, edges, corners) travel whole with half A
+bool halves_split(idx_t nx, idx_t xwidth, idx_t* q1, idx_t* q2);
+int halves_slab_ranges(int half, bool x_neighbor, idx_t lo, idx_t n, idx_t q1, idx_t q2, idx_t out_lo[2], idx_t out_n[2]);
 
 }  // namespace ykh

@@ -475,8 +475,29 @@ public:
     int planned_part(const StageMeta& sm) const;        // the stage's one part if it can run as a planned launch, else -1
     int planned_variant_of(int part) const;             // the kernel shape whose descriptor-reading twin runs the part's planned launches, or -1
     mutable std::vector<int> planned_cache_;             // ... remembered per part (-2: not looked up yet); cleared with the launch plans
-    LaunchPlan* get_launch_plan(int part, const bool* has_lo, const bool* has_hi, bool wide_shell = false);
+    LaunchPlan* get_launch_plan(int part, const bool* has_lo, const bool* has_hi, bool wide_shell = false, int mode = -1);   // mode < 0: plan_mode
     void launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hipStream_t s, bool inline_pack = false);
+    // ---- pipelined half-exchanges (-[no-]hip_halves): a stage of a decomposed rank is TWO launches in regular
+    // order, the outer x-half A = [0, q1) u [q2, nx) and the inner half B = [q1, q2) (plan mode 4), each followed by the exchange of
+    // its own part of the faces.  The exchange started behind one half is finished -- unpacked, the compute stream made to wait for
+    // it -- only after the NEXT half has been launched: A's halos are needed again by the next stage's A launch, a whole B launch
+    // later.  No shell-first order (what planned launches pay for, section 4.1), and every transfer has one launch to hide behind.
+    // Legal when what a half reads of a neighbour's data lies in the planes of that half: every written var is read face-only
+    // (l1_norm <= 1; iso3dfd, 3axis, ssg), every stage one planned part, no wave-front extension; agreed across ranks in prepare().
+    struct PhaseEvents;
+    bool halves = false;               // the option (off by default: round 3 ended before it was measured on a GPU)
+    bool halves_geom_ok_ = false;      // prepare(): legal here AND on every other rank
+    idx_t halves_q1_ = 0, halves_q2_ = 0;
+    int exch_half_ = -1;               // which slab lists exchange_halos() works on: -1 whole faces, 0 / 1 the halves
+    bool halves_in_flight_ = false;    // a half-exchange has been started and not finished
+    int halves_flight_half_ = 0;
+    PhaseEvents* halves_flight_phase_ = nullptr;
+    bool halves_geometry(idx_t* q1, idx_t* q2) const;   // this rank's box can be cut into the two halves (local; no collective)
+    bool halves_active() const;        // this run() uses the schedule (options + halves_geom_ok_ + every stage planned)
+    void launch_planned_half(int part, idx_t t, LaunchPlan& lp, int half, hipStream_t s);
+    void halves_start(int half);       // behind the launch of `half`: pack + send its faces (comm stream, after ev_shell)
+    void halves_finish();              // the exchange in flight: wait, unpack, compute stream waits for it
+    void run_stage_halves(const StageMeta& sm, int st, idx_t t, const bool* has_lo, const bool* has_hi);
     void drop_launch_plans();
     void neighbor_sides(bool* has_lo, bool* has_hi) const;
     void time_decomposed_step(const bool* has_lo, const bool* has_hi, int reps, float* ms3);
@@ -554,6 +575,9 @@ struct Slab {
 struct NeighborXfer {
     Solution::Neighbor nb;
     std::vector<Slab> send, recv;
+    // the same slabs cut at the x planes of the two halves of the pipelined schedule (Solution::halves_*; plan halves_slab_ranges):
+    // [0] what travels after the outer half's launch, [1] after the inner half's
+    std::vector<Slab> send_h[2], recv_h[2];
     void* send_buf = nullptr;
     void* recv_buf = nullptr;
     size_t send_cap = 0, recv_cap = 0;   // bytes

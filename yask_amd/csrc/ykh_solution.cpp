@@ -222,7 +222,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                                "bind_inner_threads", "bundle_allocs", "init_scratch_vars", "auto_tune",
                                "allow_addl_padding", "round_up_temporal_angles", "print_suffixes", "verbose",
                                "exchange_halos", "auto_tune_each_stage", "trace", "hip_direct_halo", "hip_thin_slab_point_kernel", "hip_round_launches",
-                               "hip_step_timers", "hip_phase_timers", "hip_fast_div", "hip_planned_launch", "hip_planned_split", "hip_inline_pack", "hip_wf_ext_always"};
+                               "hip_step_timers", "hip_phase_timers", "hip_fast_div", "hip_planned_launch", "hip_planned_split", "hip_inline_pack", "hip_wf_ext_always", "hip_halves"};
     const char* int_opts[] = {"hip_shell_pct", "hip_plan_mode", "hip_placement_trials", "hip_var_skew", "hip_step_graphs", "hip_pitch_extra", "hip_ext_streams", "hip_comm_cus", "hip_fuse_steps", "hip_overlap_splits", "min_exterior", "max_threads", "outer_threads", "inner_threads", "numa_pref",
                               "auto_tune_radius", "thread_divisor", "block_threads", "hip_xchunk", "device_thread_limit"};
     const char* dbl_opts[] = {"auto_tune_trial_secs"};
@@ -249,6 +249,7 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                     else if (b == "hip_planned_launch") planned_launch = val;
                     else if (b == "hip_planned_split") planned_split = val;
                     else if (b == "hip_inline_pack") inline_pack = val;
+                    else if (b == "hip_halves") halves = val;
                     else if (b == "hip_wf_ext_always") { wf_ext_always = val; invalidate(); }
                     else if (b == "trace") env->trace = val;
                     else if (b == "hip_direct_halo") { direct_halo = val; invalidate(); }
@@ -390,6 +391,10 @@ std::string Solution::get_command_line_help() const {
           "                                   off: one launch, the exchange released by a device-side signal that a resident wave polls)\n"
           " -[no-]hip_inline_pack             ... and the halos are packed between the two, on the compute stream (default off: the\n"
           "                                   pack kernel runs beside the second launch on the communication stream)\n"
+          " -[no-]hip_halves                  decomposed runs: a stage is TWO launches in regular order, the outer and the inner half of the\n"
+          "                                   x range, each followed by the exchange of its own part of the faces, which travels while the\n"
+          "                                   other half is computed (no shell-first order; needs face-only reads of the written vars and a\n"
+          "                                   y or z decomposition; falls back to planned launches elsewhere; default off)\n"
           " -[no-]hip_planned_launch          decomposed runs: the rank box as ONE launch of the marching kernel, shell blocks first,\n"
           "                                   the exchange released from the device when they are done (default on; off: exterior\n"
           "                                   slabs, then the interior in -hip_overlap_splits launches)\n"
@@ -736,6 +741,16 @@ void Solution::prepare() {
         interior_box = interior_for(lo, hi);
         have_interior = !interior_box.empty();
     }
+    // pipelined half-exchanges: legal on this rank?  (every written var read face-only, the box long enough in x, something left to
+    // overlap with) -- and on every other rank: the halves change what the messages hold, so all ranks take the schedule or none
+    halves_geom_ok_ = false;
+    halves_in_flight_ = false;
+    exch_half_ = -1;
+    if (env->nranks > 1) {
+        bool ok = halves_geometry(&halves_q1_, &halves_q2_) && have_interior && (num_ranks[1] > 1 || num_ranks[2] > 1);
+        for (auto& v : vars) if (v->is_written && v->l1_norm > 1) ok = false;
+        halves_geom_ok_ = env->min_over_ranks(ok ? 1 : 0) != 0;
+    }
     stats = Stats();
     prepared = true;
     if (placed && placement_trials > 1) tune_placement();
@@ -1073,6 +1088,9 @@ void Solution::time_decomposed_step(const bool* has_lo, const bool* has_hi, int 
     }
     bool all_planned = true;
     for (int st = 0; st < meta->n_stages; st++) all_planned &= planned_part(meta->stages[st]) >= 0;
+    // -hip_halves: the two half-launches of the pipelined schedule (ms[0] = the outer half, ms[1] = the inner one)
+    idx_t hq1 = 0, hq2 = 0;
+    const int plan_mode_used = (halves && halves_geometry(&hq1, &hq2)) ? 4 : -1;
     for (int r = -1; r < reps; r++) {          // r = -1: warm-up
         // (stage by stage as run() issues them; ms[0] = the exterior of the LAST stage, ms[0] + ms[1] = the whole step --
         //  with -hip_ext_streams 2 the slabs run beside the interior and their time is part of ms[1])
@@ -1082,7 +1100,7 @@ void Solution::time_decomposed_step(const bool* has_lo, const bool* has_hi, int 
             // epoch (a waiter on the comm stream, as in run()), ms[1] = from there to the end of the launch
             for (int st = 0; st < meta->n_stages; st++) {
                 const StageMeta& sm = meta->stages[st];
-                LaunchPlan* lp = get_launch_plan(planned_part(sm), has_lo, has_hi);
+                LaunchPlan* lp = get_launch_plan(planned_part(sm), has_lo, has_hi, false, plan_mode_used);
                 launch_planned(planned_part(sm), r + 1, *lp, true, compute_stream);
                 if (shell_event_pending) {
                     shell_event_pending = false;
@@ -1173,12 +1191,13 @@ int Solution::planned_variant_of(int part) const {
     }
     return remember(v);
 }
-Solution::LaunchPlan* Solution::get_launch_plan(int part, const bool* has_lo, const bool* has_hi, bool wide_shell) {
+Solution::LaunchPlan* Solution::get_launch_plan(int part, const bool* has_lo, const bool* has_hi, bool wide_shell, int mode) {
     const KernelVariant& kv = impl.parts[part].variants[planned_variant_of(part)];
+    if (mode < 0) mode = (int)plan_mode;
     std::ostringstream ks;
     ks << part << ':' << planned_variant_of(part) << '/' << local_size[0] << 'x' << local_size[1] << 'x' << local_size[2] << '/';
     for (int d = 0; d < 3; d++) ks << (has_lo[d] ? 'l' : '-') << (has_hi[d] ? 'h' : '-');
-    ks << '/' << shell_pct << '/' << plan_mode << '/' << min_exterior << '/' << env->num_cus << '/' << (wide_shell ? wf_ext_[0] + wf_ext_[1] * 1000 + wf_ext_[2] * 1000000 : 0);
+    ks << '/' << shell_pct << '/' << mode << '/' << min_exterior << '/' << env->num_cus << '/' << (wide_shell ? wf_ext_[0] + wf_ext_[1] * 1000 + wf_ext_[2] * 1000000 : 0);
     const std::string key = ks.str();
     for (auto& lp : launch_plans) if (lp->key == key) return lp.get();
     BlockPlanIn in;
@@ -1191,7 +1210,7 @@ Solution::LaunchPlan* Solution::get_launch_plan(int part, const bool* has_lo, co
     in.overhead = kv.xover > 0 ? kv.xover : std::max<idx_t>(1, shared_pad_r_[0] + 1);
     in.ncu = std::max(1, env->num_cus);
     in.shell_frac = (double)shell_pct / 100.0;
-    in.mode = (int)plan_mode;
+    in.mode = mode;
     auto lp = std::make_unique<LaunchPlan>();
     lp->key = key;
     try { lp->plan = plan_blocks(in); } catch (const PlanError& e) { YKH_THROW(e.what()); }
@@ -1209,12 +1228,20 @@ Solution::LaunchPlan* Solution::get_launch_plan(int part, const bool* has_lo, co
         for (size_t i = 0; i < lp->plan.blocks.size(); i++) if (lp->plan.blocks[i].flags & BLOCK_SIGNALS) last = i + 1;
         const size_t ncu = (size_t)std::max(1, env->num_cus);
         lp->cut = std::min(lp->plan.blocks.size(), (last + ncu - 1) / ncu * ncu);
+        if (lp->plan.mode_used == 4) lp->cut = (size_t)lp->plan.cut;       // the two halves: the planner's own cut
     }
     launch_plans.push_back(std::move(lp));
     return launch_plans.back().get();
 }
 void Solution::launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hipStream_t s, bool with_pack) {
     const KernelVariant& kv = impl.parts[part].variants[planned_variant_of(part)];
+    if (lp.plan.mode_used == 4) {        // (the two halves back to back, without their exchanges: time_decomposed_step())
+        (void)with_pack;
+        launch_planned_half(part, t, lp, 0, s);
+        if (signal) { YKH_HIP(hipEventRecord(ev_shell, s)); shell_event_pending = true; }
+        launch_planned_half(part, t, lp, 1, s);
+        return;
+    }
     PartArgs a;
     fill_part_args(part, t, rank_box(), a);
     a.blk = lp.dev;
@@ -1251,6 +1278,84 @@ void Solution::launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hi
     YKH_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------ pipelined half-exchanges (-hip_halves)
+// The reference keeps its MPI requests moving while it computes (adv_halo_exchange, src/kernel/lib/halo.cpp:494-574, called per
+// micro-block, context.cpp:1037-1040).  Planned launches (above) get their overlap from ORDER -- shell blocks first -- and pay for
+// it: tiles that march without their neighbours fetch the shared lines twice (1.05-1.13x the undivided sweep, DESIGN.md section
+// 4.1; the same blocks in regular order: 1.01-1.02x).  Here the order stays regular and the overlap comes from a software pipeline
+// over half-launches H0, H1, H2, ... (outer half A = [0, q1) u [q2, nx), inner half B = [q1, q2), A, B, ...):
+//     compute stream:  H_i            H_i+1                      H_i+2
+//     comm stream:            E_i: pack, send ... arrive, unpack --^ (H_i+2 waits for E_i; H_i+1 does not)
+// E_i carries what the neighbours need of H_i's planes: with face-only reads (l1_norm <= 1) the y / z halo a half reads lies in
+// that half's own planes, and the x faces lie in A.  Who needs E_i?  The next launch over the same planes, H_i+2 -- one whole
+// launch later.  Hazards: E_i's unpack writes halo cells of H_i's planes while H_i+1 runs; H_i+1 loads halo cells of its own
+// planes only (the marching kernels load prologue / tail planes without their halos, or never use them in a stored value), and
+// centre-only operands nowhere near a halo.  One exchange is in flight at a time: send / receive buffers and the transports'
+// per-exchange state are those of the whole-face path.
+bool Solution::halves_geometry(idx_t* q1, idx_t* q2) const {
+    if (ndd != 3 || has_outer || wf_multi()) return false;
+    return halves_split(local_size[0], std::max<idx_t>(1, std::max(shared_pad_l_[0], shared_pad_r_[0])), q1, q2);
+}
+bool Solution::halves_active() const {
+    if (!halves || !halves_geom_ok_ || !overlap_comms || !planned_launch || env->nranks <= 1 || !do_halo_exchange) return false;
+    if (std::max<idx_t>(mega_block_size[0], block_size[0]) > 1) return false;          // (wave-front groups exchange once per group)
+    for (int st = 0; st < meta->n_stages; st++)
+        if (planned_part(meta->stages[st]) < 0) return false;
+    return true;
+}
+void Solution::launch_planned_half(int part, idx_t t, LaunchPlan& lp, int half, hipStream_t s) {
+    const KernelVariant& kv = impl.parts[part].variants[planned_variant_of(part)];
+    const size_t first = half == 0 ? 0 : lp.cut, count = half == 0 ? lp.cut : lp.plan.blocks.size() - lp.cut;
+    if (count == 0) return;
+    PartArgs a;
+    fill_part_args(part, t, rank_box(), a);
+    a.blk = lp.dev + first;
+    kv.launch_desc(a, dim3((unsigned)count, 1, 1), s);
+    YKH_HIP(hipGetLastError());
+}
+// behind the launch of `half` (ev_shell has been recorded there): the comm stream waits for it, packs and sends that half's faces
+void Solution::halves_start(int half) {
+    exch_half_ = half;
+    shell_event_pending = true;
+    exchange_halos(0, 0, /*start_only=*/true, false);
+    exch_half_ = -1;
+    halves_in_flight_ = true;
+    halves_flight_half_ = half;
+    halves_flight_phase_ = cur_phase;
+}
+// the exchange in flight: the comm stream waits for its messages and unpacks them, the compute stream waits for the unpack --
+// i.e. whatever is launched AFTER this call sees the halos, what was launched before does not wait
+void Solution::halves_finish() {
+    if (!halves_in_flight_) return;
+    PhaseEvents* mine = cur_phase;
+    cur_phase = halves_flight_phase_;          // (transfer / unpack times belong to the phase set of the launch that produced the data)
+    exch_half_ = halves_flight_half_;
+    try { exchange_halos(0, 0, false, /*finish_only=*/true); } catch (...) { exch_half_ = -1; cur_phase = mine; halves_in_flight_ = false; throw; }
+    exch_half_ = -1;
+    cur_phase = mine;
+    halves_in_flight_ = false;
+    // (the inner half completes the faces: nothing is dirty any more -- also when this rank had no message in this exchange)
+    if (halves_flight_half_ == 1)
+        for (auto& v : vars) v->set_dirty_all(false);
+}
+void Solution::run_stage_halves(const StageMeta& sm, int /*st*/, idx_t t, const bool* has_lo, const bool* has_hi) {
+    const int part = planned_part(sm);
+    LaunchPlan* lp = get_launch_plan(part, has_lo, has_hi, false, /*mode=*/4);
+    for (int h = 0; h < 2; h++) {
+        cur_phase = phase_next();
+        phase_mark(PH_EXT0, compute_stream);
+        launch_planned_half(part, t, *lp, h, compute_stream);
+        YKH_HIP(hipEventRecord(ev_shell, compute_stream));
+        phase_mark(PH_INT1, compute_stream);
+        halves_finish();                       // the PREVIOUS half's exchange (its data are first read by the launch after this one)
+        phase_mark(PH_WAIT1, compute_stream);  // INT1 -> WAIT1: what the compute stream will idle behind this launch = exchange not hidden
+        // (host bookkeeping, after the previous stage's flags have been cleared: what this stage writes is dirty for both halves)
+        if (h == 0) note_stage_written(sm, t);
+        halves_start(h);                       // (marks EXT1 on the comm stream, behind its wait for this launch: EXT0 -> EXT1 = the launch)
+        cur_phase = nullptr;
+    }
+}
+
 // ------------------------------------------------------------------ phase timers
 // The reference times halo pack / unpack / wait and exterior / interior evaluation with host timers
 // (src/kernel/lib/context.hpp:319-328); here the phases are asynchronous, so each (step, stage) of a multi-rank run
@@ -1260,6 +1365,7 @@ Solution::PhaseEvents* Solution::phase_next() {
     // A ring: run_solution(0, 99999) must not create 800 000 events.  Set number k of a run lives in slot k % PHASE_RING; before
     // a slot is reused its times are folded into `stats` (its events are PHASE_RING stages old: the wait is almost never one).
     const size_t slot = phase_used % PHASE_RING;
+    phase_pool.reserve(PHASE_RING);          // (sets are handed out by pointer, and the halves schedule holds two at a time: never re-allocate)
     if (slot == phase_pool.size()) {
         PhaseEvents ph;
         for (int i = 0; i < PH_N; i++) { ph.e[i] = nullptr; ph.rec[i] = false; }
@@ -1707,13 +1813,20 @@ void Solution::run(idx_t first_step, idx_t last_step) {
         // bookkeeping of the replayed steps: what the plain loop does per step; the last two periods decide the final state
         for (idx_t k = std::min<idx_t>(done, 2 * P); k >= 1; k--) note_step_written(t_plain - dir * k);
     }
+    const bool halves_on = multi && halves_active();
+    halves_in_flight_ = false;
     for (idx_t t = t_plain; !wavefront && (dir > 0 ? t <= last_step : t >= last_step); t += dir) {
         for (int st = 0; st < meta->n_stages; st++) {
             const StageMeta& sm = meta->stages[st];
-            const bool overlap = multi && overlap_comms && have_interior;
-            cur_phase = multi ? phase_next() : nullptr;
             bool lo[MAX_DOMAIN_DIMS], hi[MAX_DOMAIN_DIMS];
             neighbor_sides(lo, hi);
+            if (halves_on) {
+                // two launches in regular order, each followed by the exchange of its part of the faces (run_stage_halves)
+                run_stage_halves(sm, st, t, lo, hi);
+                continue;
+            }
+            const bool overlap = multi && overlap_comms && have_interior;
+            cur_phase = multi ? phase_next() : nullptr;
             // (x-only decompositions keep the slab schedule: their faces are whole planes, the two thin slabs cost 2-14 % where
             //  cutting every tile into rounds costs 4-40 %, tools/decomp_cost.py)
             const int pl_part = (overlap && (lo[1] || hi[1] || lo[2] || hi[2])) ? planned_part(sm) : -1;
@@ -1763,6 +1876,14 @@ void Solution::run(idx_t first_step, idx_t last_step) {
         }
         nsteps++;
         if (step_timers) YKH_HIP(hipEventRecord(step_events[nsteps], compute_stream));
+    }
+    if (halves_in_flight_) {
+        // the last half-exchange of the run: nothing left to hide it behind
+        cur_phase = phase_next();
+        phase_mark(PH_INT1, compute_stream);
+        halves_finish();
+        phase_mark(PH_WAIT1, compute_stream);
+        cur_phase = nullptr;
     }
     YKH_HIP(hipStreamSynchronize(compute_stream));
     if (multi) YKH_HIP(hipStreamSynchronize(comm_stream));
