@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--stencil", default="iso3dfd")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--cases", type=int, default=99, help="only the first N cases")
-    ap.add_argument("--schedules", default="", help="only the schedules whose label contains this text")
+    ap.add_argument("--schedules", default="", help="only the schedules whose label contains this text (comma-separated alternatives)")
     ap.add_argument("--tag", default="")
     args = ap.parse_args()
     from yask_amd import yk_factory
@@ -60,7 +60,7 @@ def main():
         s.run_solution(10, 10 + args.steps - 1)
         one_ms = (time.perf_counter() - t0) / args.steps * 1e3
         s.end_solution()
-        for label, opts in [x for x in SCHEDULES if args.schedules in x[0]]:
+        for label, opts in [x for x in SCHEDULES if any(k in x[0] for k in args.schedules.split(","))]:
             env = fac.new_env()
             env.init_mirror(rank, world)
             s = fac.new_solution(env)
