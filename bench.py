@@ -291,6 +291,11 @@ def main():
     ap.add_argument("--decomp", default=None, choices=["xslab", "compact"],
                     help="compact: the reference's most-compact rank grid (8 -> 2x2x2; default for c2 and c4); "
                          "xslab: N x 1 x 1 ranks, contiguous whole-plane faces, 2 neighbours per GPU (default for weak)")
+    ap.add_argument("--rank-grid", dest="rank_grid", type=int, nargs=3, default=None, metavar=("RX", "RY", "RZ"),
+                    help="explicit rank grid (the reference's -nrx/-nry/-nrz; product = --gpus).  Measured on one GPU under an emulated "
+                         "50 GB/s link (tools/overlap_probe.py --grid-study, profiles/r3_halves): 1024^3 on 8 GPUs is fastest on the "
+                         "compact 2x2x2 grid, 2048x2048x1024 on 4x2x1 (no z cut: +7 %%); with --config c4 and 8 ranks the global grid "
+                         "stays 2 --size x 2 --size x --size")
     ap.add_argument("--points-per-gpu", dest="local", type=int, nargs=3, default=None, metavar=("NX", "NY", "NZ"),
                     help="explicit points per GPU per dim (overrides --config / --size)")
     ap.add_argument("--transport", default="auto", choices=["auto", "ipc", "rccl", "torch"],
@@ -346,12 +351,18 @@ def main():
         silently be measured on another transport, VERDICT r01 weak #8)"""
         env_, used = ydist.new_env(fac, transport_name, strict=True)
         so = fac.new_solution(env_)
-        if decomp == "xslab":
+        if args.rank_grid:
+            if args.rank_grid[0] * args.rank_grid[1] * args.rank_grid[2] != world:
+                raise SystemExit(f"bench.py: --rank-grid {args.rank_grid} does not hold {world} ranks")
+            so.set_num_ranks_vec(list(args.rank_grid))
+        elif decomp == "xslab":
             so.set_num_ranks_vec([world, 1, 1])
         if args.local:
             so.set_rank_domain_size_vec(list(args.local))
         elif args.config == "c2":
             so.set_overall_domain_size_vec([n, n, n])
+        elif args.config == "c4" and args.rank_grid and world == 8:
+            so.set_overall_domain_size_vec([2 * n, 2 * n, n])      # BASELINE config 4's global grid, cut the way --rank-grid says
         elif args.config == "c4":
             so.set_rank_domain_size_vec([n, n, n // 2])
         else:
@@ -549,7 +560,7 @@ def main():
             "config": {"workload": f"{descr}, global {glob_sz[0]}x{glob_sz[1]}x{glob_sz[2]}, {local[0]}x{local[1]}x{local[2]} points per GPU",
                        "baseline_config": {"c2": "configs[1] (1024^3 global)", "c4": "configs[3] (1024x1024x512 per GPU, compact grid)",
                                            "weak": "one block per GPU"}[args.config] if not args.local else "explicit --points-per-gpu",
-                       "decomposition": ("x-slabs " if decomp == "xslab" else "compact rank grid ") + "x".join(str(g) for g in grid),
+                       "decomposition": ("rank grid (--rank-grid) " if args.rank_grid else "x-slabs " if decomp == "xslab" else "compact rank grid ") + "x".join(str(g) for g in grid),
                        "halo_transport": transport, "transport_trials_ms_per_step": transport_ms,
                        "kernel": "+".join(soln.get_kernel_variant(p) for p in range(nparts)),
                        "overlap_comms": (schedule != "serial") if world > 1 else None,

@@ -23,6 +23,18 @@ CASES = {  # name -> (global size, rank grid, rank played)
     "ssg": [("ssg 1024^3 / 8 GPUs 2x2x2: 512^3 block", (1024, 1024, 1024), (2, 2, 2), 0),
             ("ssg 512^3 / 8 GPUs 2x2x2: 256^3 block", (512, 512, 512), (2, 2, 2), 0)],
 }
+# Which rank grid for 8 GPUs?  The reference's default is the most compact one (2x2x2, get_compact_factors, src/common/tuple.cpp:355-430);
+# `-nr*` lets the user choose.  Grids that do not cut z have no z face (32-byte runs: the expensive pack / unpack, the column of
+# shell tiles) but more halo bytes; x faces travel in place.  The rank played is the one with the most neighbours.
+GRID_CASES = [("c2 1024^3 / 2x2x2: 512^3 block", (1024, 1024, 1024), (2, 2, 2), 0),
+              ("c2 1024^3 / 2x4x1: 512x256x1024 block, y both sides", (1024, 1024, 1024), (2, 4, 1), 2),
+              ("c2 1024^3 / 4x2x1: 256x512x1024 block, x both sides", (1024, 1024, 1024), (4, 2, 1), 1),
+              ("c2 1024^3 / 1x4x2: 1024x256x512 block", (1024, 1024, 1024), (1, 4, 2), 1),
+              ("c2 1024^3 / 8x1x1: 128x1024x1024 block, x both sides", (1024, 1024, 1024), (8, 1, 1), 1),
+              ("c4 2048x2048x1024 / 2x2x2: 1024x1024x512 block", (2048, 2048, 1024), (2, 2, 2), 0),
+              ("c4 2048x2048x1024 / 2x4x1: 1024x512x1024 block", (2048, 2048, 1024), (2, 4, 1), 2),
+              ("c4 2048x2048x1024 / 4x2x1: 512x1024x1024 block", (2048, 2048, 1024), (4, 2, 1), 1),
+              ("c4 2048x2048x1024 / 8x1x1: 256x2048x1024 block", (2048, 2048, 1024), (8, 1, 1), 1)]
 SCHEDULES = [("halves: two launches in regular order, half-exchanges pipelined (-hip_halves)", "-overlap_comms -hip_planned_launch -hip_halves"),
              ("planned (rounds, shell first)", "-overlap_comms -hip_planned_launch"),
              ("planned, pack in line on the compute stream (-hip_inline_pack)", "-overlap_comms -hip_planned_launch -hip_inline_pack"),
@@ -39,13 +51,14 @@ def main():
     ap.add_argument("--cases", type=int, default=99, help="only the first N cases")
     ap.add_argument("--schedules", default="", help="only the schedules whose label contains this text (comma-separated alternatives)")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--grid-study", action="store_true", help="iso3dfd: the 8-GPU rank grids of GRID_CASES instead of the default cases")
     args = ap.parse_args()
     from yask_amd import yk_factory
     from yask_amd.kernel import yk_env
     yk_env.disable_debug_output()
     fac = yk_factory(args.stencil)
     out = []
-    for name, g, nr, rank in CASES[args.stencil][:args.cases]:
+    for name, g, nr, rank in (GRID_CASES if args.grid_study else CASES[args.stencil])[:args.cases]:
         world = nr[0] * nr[1] * nr[2]
         local = [g[d] // nr[d] for d in range(3)]
         # reference: the same block as a one-rank job
@@ -84,7 +97,8 @@ def main():
                    "pack_ms": round(st.get_halo_pack_secs() / n * 1e3, 4), "copy_ms": round(st.get_halo_xfer_secs() / n * 1e3, 4),
                    "unpack_ms": round(st.get_halo_unpack_secs() / n * 1e3, 4), "exposed_wait_ms": round(st.get_halo_wait_secs() / n * 1e3, 4),
                    "comm_hidden_fraction": round(max(0.0, 1.0 - st.get_halo_wait_secs() / comm), 3) if comm > 0 else None,
-                   "halo_MB_per_step": round(st.get_halo_bytes_sent() / n / 1e6, 2)}
+                   "halo_MB_per_step": round(st.get_halo_bytes_sent() / n / 1e6, 2), "rank_grid": list(nr), "rank": rank,
+                   "job_gpoints_per_s_at_8_ranks": round(g[0] * g[1] * g[2] / ms * 1e-6, 1)}
             out.append(rec)
             print(json.dumps(rec), flush=True)
             s.end_solution()
