@@ -29,14 +29,14 @@ SSG_CASES = [
 CONFIGS = [  # label, options
     # round 3, late: the pipelined half-exchange schedule -- outer x-half, inner x-half, regular order (shell_ms = the outer half)
     ("halves: two launches in regular order (-hip_halves)", "-hip_planned_launch -hip_halves"),
-    ("planned rounds pct55 (default)", "-hip_planned_launch -hip_shell_pct 55 -hip_plan_mode 0"),
-    ("planned rounds pct35", "-hip_planned_launch -hip_shell_pct 35 -hip_plan_mode 0"),
-    ("planned, one round if shortest (pct100: descriptors + signals, no early shell)", "-hip_planned_launch -hip_shell_pct 100 -hip_plan_mode 0"),
-    ("planned rounds pct55, blocks in regular-launch order (shell not first)", "-hip_planned_launch -hip_shell_pct 55 -hip_plan_mode 3"),
-    ("first planner: thin x slabs + per-CU budgets", "-hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 1"),
-    ("first planner: uniform interior chunks", "-hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 2"),
-    ("slabs, interior in 2 launches (round 2 default)", "-no-hip_planned_launch -hip_overlap_splits 2"),
-    ("slabs, interior in 1 launch", "-no-hip_planned_launch -hip_overlap_splits 1"),
+    ("planned rounds pct55 (default)", "-no-hip_halves -hip_planned_launch -hip_shell_pct 55 -hip_plan_mode 0"),
+    ("planned rounds pct35", "-no-hip_halves -hip_planned_launch -hip_shell_pct 35 -hip_plan_mode 0"),
+    ("planned, one round if shortest (pct100: descriptors + signals, no early shell)", "-no-hip_halves -hip_planned_launch -hip_shell_pct 100 -hip_plan_mode 0"),
+    ("planned rounds pct55, blocks in regular-launch order (shell not first)", "-no-hip_halves -hip_planned_launch -hip_shell_pct 55 -hip_plan_mode 3"),
+    ("first planner: thin x slabs + per-CU budgets", "-no-hip_halves -hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 1"),
+    ("first planner: uniform interior chunks", "-no-hip_halves -hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 2"),
+    ("slabs, interior in 2 launches (round 2 default)", "-no-hip_halves -no-hip_planned_launch -hip_overlap_splits 2"),
+    ("slabs, interior in 1 launch", "-no-hip_halves -no-hip_planned_launch -hip_overlap_splits 1"),
     # compute side of the multi-rank wave-front tiling: one step's share of a 2-step group on extended, shrinking boxes
     ("wave-front tiling across ranks, -Mbt 2 (per step)", "-Mbt 2 -hip_wf_ext_always"),
 ]

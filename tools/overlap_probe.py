@@ -36,11 +36,11 @@ GRID_CASES = [("c2 1024^3 / 2x2x2: 512^3 block", (1024, 1024, 1024), (2, 2, 2), 
               ("c4 2048x2048x1024 / 4x2x1: 512x1024x1024 block", (2048, 2048, 1024), (4, 2, 1), 1),
               ("c4 2048x2048x1024 / 8x1x1: 256x2048x1024 block", (2048, 2048, 1024), (8, 1, 1), 1)]
 SCHEDULES = [("halves: two launches in regular order, half-exchanges pipelined (-hip_halves)", "-overlap_comms -hip_planned_launch -hip_halves"),
-             ("planned (rounds, shell first)", "-overlap_comms -hip_planned_launch"),
-             ("planned, pack in line on the compute stream (-hip_inline_pack)", "-overlap_comms -hip_planned_launch -hip_inline_pack"),
-             ("planned, one launch + device-side signal (-no-hip_planned_split)", "-overlap_comms -hip_planned_launch -no-hip_planned_split"),
-             ("planned, shell by 35 %", "-overlap_comms -hip_planned_launch -hip_shell_pct 35"),
-             ("slabs + interior (round 2)", "-overlap_comms -no-hip_planned_launch"),
+             ("planned (rounds, shell first)", "-overlap_comms -hip_planned_launch -no-hip_halves"),
+             ("planned, pack in line on the compute stream (-hip_inline_pack)", "-overlap_comms -hip_planned_launch -no-hip_halves -hip_inline_pack"),
+             ("planned, one launch + device-side signal (-no-hip_planned_split)", "-overlap_comms -hip_planned_launch -no-hip_halves -no-hip_planned_split"),
+             ("planned, shell by 35 %", "-overlap_comms -hip_planned_launch -no-hip_halves -hip_shell_pct 35"),
+             ("slabs + interior (round 2)", "-overlap_comms -no-hip_planned_launch -no-hip_halves"),
              ("whole box, then exchange", "-no-overlap_comms")]
 
 
