@@ -175,6 +175,92 @@ def test_emulated_rank_grid_equals_single_rank(nranks, num_ranks):
     assert np.array_equal(got, ref)          # identical arithmetic on identical inputs: bit-exact
 
 
+# ------------------------------------------------------------------ (b2) the pipelined half-exchange schedule, emulated
+def _emulate_iso3dfd_halves(nranks, g, steps, num_ranks, deliver):
+    """Solution::run_stage_halves() in numpy: every rank steps its box in two launches -- the outer x-half [0, q1) u [q2, nx), then
+    the inner half -- with the oracle's arithmetic; behind each goes the exchange of that half's part of the faces, cut by the
+    library's own yk_plan_halves / yk_plan_halves_slab.  `deliver`: "late" = a half's messages land only after the NEXT half has
+    been computed (what the library does: the next launch does not wait for them), "early" = they land before it (what a fast link
+    does while that launch runs).  If both orders give the one-rank result bit for bit, the launch after a half-exchange neither
+    needs nor disturbs it, and the launch after that finds everything it reads."""
+    plans = [plan(nranks, r, g, num_ranks=num_ranks) for r in range(nranks)]
+    ids, init = O.VAR_IDS["iso3dfd"], O.DEFAULT_INIT["iso3dfd"]
+    st, cuts = [], []
+    for p in plans:
+        ls, ofs = tuple(p.local_size), tuple(p.rank_offset)
+        pp = [O.fill(ls, H, ids["p"], s, *init["p"], dtype=np.float32, origin=ofs) for s in (0, 1)]
+        v = O.fill(ls, H, ids["v"], 0, *init["v"], dtype=np.float32, origin=ofs)
+        st.append((pp, v, ls))
+        q1, q2 = _capi.idx_t(), _capi.idx_t()
+        assert _lib().yk_plan_halves(ls[0], H, C.byref(q1), C.byref(q2)) == 1, "box too short in x for this test"
+        cuts.append((q1.value, q2.value))
+    fn = O.lib().yo_iso3dfd_step_f32
+
+    def launch(r, t, half):
+        (pp, v, ls), (q1, q2) = st[r], cuts[r]
+        src, dst = pp[t % 2], pp[(t + 1) % 2]
+        for a, b in ([(0, q1), (q2, ls[0])] if half == 0 else [(q1, q2)]):
+            # the planes [a, b) with their x neighbours: a contiguous copy the oracle's whole-box step can work on
+            s_sub, d_sub, v_sub = (np.ascontiguousarray(x[a:b + 2 * H]) for x in (src, dst, v))
+            fn(O._ptr(s_sub), O._ptr(d_sub), O._ptr(v_sub), C.c_int64(b - a), C.c_int64(ls[1]), C.c_int64(ls[2]), C.c_int64(H), C.c_int(8))
+            dst[a + H:b + H, H:-H, H:-H] = O.interior(d_sub, H)
+
+    def pieces(r, o, sending, half):
+        sl = slab(plans[r], o, sending=sending)
+        if sl is None:
+            return []
+        (f, sz), (q1, q2) = sl, cuts[r]
+        out4 = (_capi.idx_t * 4)()
+        k = _lib().yk_plan_halves_slab(half, 1 if o[0] != 0 else 0, f[0], sz[0], q1, q2, out4)
+        return [((out4[2 * i], f[1], f[2]), (out4[2 * i + 1], sz[1], sz[2])) for i in range(k)]
+
+    def collect(t, half):        # what every rank sends behind this half: copies taken NOW (the pack kernel)
+        msgs = {}
+        for r in range(nranks):
+            a = st[r][0][(t + 1) % 2]
+            for nr, o in neighbors(plans[r]):
+                msgs[(r, nr)] = [a[tuple(slice(H + f[d], H + f[d] + sz[d]) for d in range(3))].copy() for f, sz in pieces(r, o, True, half)]
+        return (t, half, msgs)
+
+    def land(flight):            # ... and where they land (the unpack kernel)
+        t, half, msgs = flight
+        for r in range(nranks):
+            a = st[r][0][(t + 1) % 2]
+            for nr, o in neighbors(plans[r]):
+                got = msgs[(nr, r)]
+                mine = pieces(r, o, False, half)
+                assert len(got) == len(mine), "the two ends of a link cut the face differently"
+                for m, (f, sz) in zip(got, mine):
+                    assert m.shape == tuple(sz)
+                    a[tuple(slice(H + f[d], H + f[d] + sz[d]) for d in range(3))] = m
+
+    flight = None
+    for t in range(steps):
+        for half in (0, 1):
+            if flight is not None and deliver == "early":
+                land(flight); flight = None
+            for r in range(nranks):
+                launch(r, t, half)
+            if flight is not None:
+                land(flight)                     # finished only now: the launch above did not wait for it
+            flight = collect(t, half)
+    land(flight)
+    out = np.zeros(g, np.float32)
+    for p, (pp, v, ls) in zip(plans, st):
+        o = tuple(p.rank_offset)
+        out[o[0]:o[0] + ls[0], o[1]:o[1] + ls[1], o[2]:o[2] + ls[2]] = O.interior(pp[steps % 2], H)
+    return out
+
+
+@pytest.mark.parametrize("deliver", ["late", "early"])
+@pytest.mark.parametrize("nranks,num_ranks,g", [(8, (2, 2, 2), (64, 36, 44)), (4, (1, 2, 2), (40, 36, 44)), (4, (2, 2, 1), (70, 36, 30))])
+def test_emulated_pipelined_half_exchanges_equal_single_rank(nranks, num_ranks, g, deliver):
+    steps = 3
+    ref = O.run_iso3dfd(g, steps)[("p", steps)]
+    got = _emulate_iso3dfd_halves(nranks, g, steps, num_ranks, deliver)
+    assert np.array_equal(got, ref)
+
+
 # ------------------------------------------------------------------ (c) real processes, gloo, world size 2
 def _free_port():
     s = socket.socket()
