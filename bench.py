@@ -19,8 +19,9 @@ N>1 is launched by the driver as `python -m torch.distributed.run ... bench.py -
 Halos travel either as device-to-device copies into the neighbour's buffers through HIP IPC handles (no CU, no host in the
 loop) or as RCCL send/recv on a side stream: both are set up and timed during warm-up and the faster one is kept (--transport
 auto; config.transport / transport_trials_ms).  The rank box is ONE planned launch (shell blocks first, the exchange released from
-the device) or round 2's slab / serial schedules: the four are timed during warm-up as well (--schedule auto, timings in the JSON
-line); a failing transport set-up is an error, not a fallback.  Rank 0 prints ONE JSON line.  roofline.traffic is measured live
+the device), two launches in regular order with pipelined half-exchanges ("halves"), or round 2's slab / serial schedules: all
+candidates are timed during warm-up as well (--schedule auto, timings in the JSON line); --rank-grid RX RY RZ replaces the compact
+rank grid; a failing transport set-up is an error, not a fallback.  Rank 0 prints ONE JSON line.  roofline.traffic is measured live
 (two rocprofv3 --pmc passes of the same workload after the timed region, N=1 only; --traffic off skips them).
 prepare_solution() draws several sets of var allocations, times a step on each and keeps the fastest (config.var_placement).
 
