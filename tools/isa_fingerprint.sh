@@ -12,8 +12,8 @@ for s in $S; do
   for f in stencil_${s}.hip stencil_${s}_k*.hip; do
     [ -f "$f" ] || continue
     ( hipcc -O3 -std=c++17 --offload-arch=gfx950 -I. --cuda-device-only -S "$f" -o "$T/$f.s" 2>/dev/null &&
-      # (the assembly carries no paths or time stamps; .ident names the compiler build)
-      echo "$f $(grep -v '^\s*\.ident' "$T/$f.s" | sha256sum | cut -d' ' -f1) $(grep -c '^\s*\.amdhsa_kernel ' "$T/$f.s") kernels" > "$T/$f.txt" ) &
+      # (the assembly carries no paths or time stamps; .ident names the compiler build, __hip_cuid_<random> is a per-compilation id)
+      echo "$f $(grep -v '^\s*\.ident' "$T/$f.s" | sed 's/__hip_cuid_[0-9a-f]*/__hip_cuid_X/g' | sha256sum | cut -d' ' -f1) $(grep -c '^\s*\.amdhsa_kernel ' "$T/$f.s") kernels" > "$T/$f.txt" ) &
     while [ "$(jobs -r | wc -l)" -ge 8 ]; do sleep 0.2; done
   done
 done
