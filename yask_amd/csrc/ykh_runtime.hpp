@@ -346,9 +346,10 @@ public:
     idx_t overlap_splits = 1;      // -hip_overlap_splits: interior launches per stage of the slab schedule (each split re-runs the
                                    // 16-plane prologue: iso3dfd 512^3 interior 0.355 / 0.387 / 0.472 ms at 1 / 2 / 4).  1 since round 3:
                                    // the splits were there to let RCCL's kernels in between launches, which the copy-based IPC
-                                   // transport does not need; and at 1024^3 a run with 2 splits differs from the one-rank run in the
-                                   // last bit of ~0.2 % of the points per step (1 split, the planned launches and -no-overlap_comms
-                                   // are bit-identical: tools/diag_bitexact.py, gpurun_out/r3c) -- inside the tolerance, cause not found
+                                   // transport does not need.  (At 1024^3 a run with 2 splits used to differ from the one-rank run in the
+                                   // last bit of ~0.2 % of the points per step: the parity of an x-chunk start selected a differently
+                                   // contracted first add of the partial sums; explicit FMAs since -- ykh_device.hpp fmacc -- and every
+                                   // split is bit-identical, tests/test_decomposed_blocks_gpu.py)
     idx_t ext_streams_mode = 0;    // -hip_ext_streams: 0 = exterior slabs one after another on the compute stream (default); 1 = every
                                    // slab on its own stream, side by side, the interior after them; 2 = the interior beside them as
                                    // well (the exchange waits for the slabs only).  Measured on one GPU (profiles/r02r_ext_streams):
