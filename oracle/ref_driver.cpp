@@ -16,10 +16,16 @@
 // Output (-out PREFIX): PREFIX.json manifest + one raw little-endian file per (var, valid step)
 // holding the rank-domain box, row-major in the var's own dim order (last dim fastest).
 //
+// With -lattice STRIDE the files hold only the sample oracle.py lattice() defines -- every point of the 9-wide boundary layers
+// plus every STRIDE-th point per domain dim -- read plane by plane, so that grids of tens of GB (BASELINE config 4's global
+// 2048 x 2048 x 1024) never exist twice in memory; the manifest's shape is then the lattice's.  Initialisation goes slab by slab
+// along the outermost domain dim for the same reason.
+//
 // Usage: ref_driver.<tag>.exe -g NX [NY NZ] -steps N [-first T0] [-threads T] [-init v:150:50]...
-//                             [-out PREFIX] [-trials K] [-opts "<yask options>"] [-reverse]
+//                             [-out PREFIX] [-lattice STRIDE] [-trials K] [-opts "<yask options>"] [-reverse]
 
 #include "yask_kernel_api.hpp"
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -53,6 +59,7 @@ int main(int argc, char** argv) {
     idx_t nsteps = 1, first_t = 0;
     int threads = 0, trials = 1;
     bool reverse = false;     // run_solution(first, first - steps + 1): step indices descend (reverse-time stencils)
+    idx_t lattice_stride = 0; // > 0: -out writes the lattice sample only
     string out_prefix, extra_opts;
     std::map<string, InitSpec> specs;
     for (int i = 1; i < argc; i++) {
@@ -65,6 +72,7 @@ int main(int argc, char** argv) {
         else if (a == "-trials") { need(1); trials = atoi(argv[++i]); }
         else if (a == "-reverse") reverse = true;
         else if (a == "-out") { need(1); out_prefix = argv[++i]; }
+        else if (a == "-lattice") { need(1); lattice_stride = atoll(argv[++i]); }
         else if (a == "-opts") { need(1); extra_opts = argv[++i]; }
         else if (a == "-init") {
             need(1);
@@ -123,6 +131,17 @@ int main(int argc, char** argv) {
                     else { first[i] = v->get_first_misc_index(dn[i]); last[i] = v->get_last_misc_index(dn[i]); }
                 }
             }
+            // slab by slab along the outermost domain dim (and step by step), at most ~32 M elements in the staging buffer
+            const idx_t_vec first_all = first, last_all = last;
+            const int split = dom_posn[0] >= 0 ? dom_posn[0] : -1;
+            size_t per_plane = 1;
+            for (int i = 0; i < nd; i++) if (i != split && i != step_posn) per_plane *= (size_t)(last_all[i] - first_all[i] + 1);
+            const idx_t chunk = split >= 0 ? std::max<idx_t>(1, (idx_t)((size_t)(32u << 20) / std::max<size_t>(1, per_plane))) : 1;
+            for (idx_t tt = (step_posn >= 0 ? first_all[step_posn] : 0); tt <= (step_posn >= 0 ? last_all[step_posn] : 0); tt++)
+            for (idx_t s0 = (split >= 0 ? first_all[split] : 0); s0 <= (split >= 0 ? last_all[split] : 0); s0 += chunk) {
+            first = first_all; last = last_all;
+            if (step_posn >= 0) first[step_posn] = last[step_posn] = tt;
+            if (split >= 0) { first[split] = s0; last[split] = std::min(last_all[split], s0 + chunk - 1); }
             size_t n = 1; vector<idx_t> ext(nd);
             for (int i = 0; i < nd; i++) { ext[i] = last[i] - first[i] + 1; n *= (size_t)ext[i]; }
             vector<double> buf(n);
@@ -144,6 +163,7 @@ int main(int argc, char** argv) {
                 for (int i = nd - 1; i >= 0; i--) { if (++idx[i] <= last[i]) break; idx[i] = first[i]; }
             }
             v->set_elements_in_slice(buf.data(), n, first, last);
+            }
             vid++;
         }
     };
@@ -187,17 +207,53 @@ int main(int argc, char** argv) {
             }
             idx_t t_lo = 0, t_hi = 0;
             if (step_posn >= 0) { t_lo = v->get_first_valid_step_index(); t_hi = v->get_last_valid_step_index(); }
+            // (-lattice: only step-indexed vars over three domain dims are sampled -- the wavefields; coefficient vars are inputs)
+            if (lattice_stride > 0 && !(step_posn >= 0 && nd == 4)) continue;
             for (idx_t t = t_lo; t <= t_hi; t++) {
                 if (step_posn >= 0) first[step_posn] = last[step_posn] = t;
                 size_t n = 1; for (int i = 0; i < nd; i++) n *= (size_t)(last[i] - first[i] + 1);
                 std::ostringstream fn; fn << out_prefix << "." << v->get_name() << ".t" << t << ".bin";
                 std::ofstream f(fn.str(), std::ios::binary);
-                if (esz == 4) { vector<float> b(n); v->get_elements_in_slice(b.data(), n, first, last); f.write((char*)b.data(), n * 4); }
+                vector<idx_t> shape_out;
+                for (int i = 0; i < nd; i++) if (i != step_posn) shape_out.push_back(last[i] - first[i] + 1);
+                // position of the domain dims among the var's dims, outermost first
+                vector<int> dpos;
+                for (int i = 0; i < nd; i++) { bool is_dom = false; for (auto& d : ddims) is_dom |= (d == dn[i]); if (is_dom) dpos.push_back(i); }
+                if (lattice_stride > 0 && step_posn >= 0 && dpos.size() == 3 && nd == 4) {
+                    // the lattice sample only, read plane by plane of the outermost domain dim (oracle.py lattice(): edge 9)
+                    auto lat = [&](idx_t lo, idx_t hi) {
+                        const idx_t nn = hi - lo + 1, edge = 9;
+                        vector<char> take((size_t)nn, 0);
+                        for (idx_t k = 0; k < std::min(edge, nn); k++) take[k] = 1;
+                        for (idx_t k = 0; k < nn; k += lattice_stride) take[k] = 1;
+                        for (idx_t k = std::max<idx_t>(0, nn - edge); k < nn; k++) take[k] = 1;
+                        vector<idx_t> out;
+                        for (idx_t k = 0; k < nn; k++) if (take[k]) out.push_back(lo + k);
+                        return out;
+                    };
+                    const vector<idx_t> lx = lat(first[dpos[0]], last[dpos[0]]), ly = lat(first[dpos[1]], last[dpos[1]]), lz = lat(first[dpos[2]], last[dpos[2]]);
+                    const idx_t y0 = first[dpos[1]], z0 = first[dpos[2]], nz = last[dpos[2]] - first[dpos[2]] + 1;
+                    const size_t plane = (size_t)(last[dpos[1]] - first[dpos[1]] + 1) * (size_t)nz;
+                    vector<float> pf; vector<double> pd;
+                    if (esz == 4) pf.resize(plane); else pd.resize(plane);
+                    for (idx_t x : lx) {
+                        idx_t_vec pfirst = first, plast = last;
+                        pfirst[dpos[0]] = plast[dpos[0]] = x;
+                        if (esz == 4) v->get_elements_in_slice(pf.data(), plane, pfirst, plast); else v->get_elements_in_slice(pd.data(), plane, pfirst, plast);
+                        for (idx_t y : ly)
+                            for (idx_t z : lz) {
+                                const size_t o = (size_t)(y - y0) * (size_t)nz + (size_t)(z - z0);
+                                if (esz == 4) f.write((char*)&pf[o], 4); else f.write((char*)&pd[o], 8);
+                            }
+                    }
+                    shape_out = {(idx_t)lx.size(), (idx_t)ly.size(), (idx_t)lz.size()};
+                }
+                else if (esz == 4) { vector<float> b(n); v->get_elements_in_slice(b.data(), n, first, last); f.write((char*)b.data(), n * 4); }
                 else { vector<double> b(n); v->get_elements_in_slice(b.data(), n, first, last); f.write((char*)b.data(), n * 8); }
                 man << (firstv ? "" : ", ") << "{\"name\": \"" << v->get_name() << "\", \"step\": " << t << ", \"has_step\": "
                     << (step_posn >= 0 ? "true" : "false") << ", \"shape\": [";
                 bool f1 = true;
-                for (int i = 0; i < nd; i++) if (i != step_posn) { man << (f1 ? "" : ", ") << (last[i] - first[i] + 1); f1 = false; }
+                for (idx_t e : shape_out) { man << (f1 ? "" : ", ") << e; f1 = false; }
                 man << "], \"file\": \"" << fn.str().substr(fn.str().find_last_of('/') + 1) << "\"}";
                 firstv = false;
             }
