@@ -34,3 +34,28 @@ def test_iso3dfd_config4_global_grid_over_eight_ranks_matches_the_reference(gpu,
     ref = np.load(G / "c4_iso3dfd_2048x2048x1024_s2_lattice.npz")[f"p@{steps}"].astype(np.float64)
     err = np.abs(full.astype(np.float64) - ref).max() / max(1.0, np.abs(ref).max())
     assert full.shape == ref.shape and err <= 2e-5, err
+
+
+def test_3axis_fp64_1024_matches_the_reference_lattice(gpu):
+    """3axis r=4 fp64 at 1024^3 -- the size bench.py also runs it at, where prepare_solution() picks the 128 x 32 large-grid tile --
+    against the unmodified reference on the lattice (<= 1e-12, the fp64 bound of DESIGN.md section 5)."""
+    from yask_amd import yk_factory
+    meta = INDEX["c3_3axis_fp64_1024_s4_lattice"]
+    g, steps, stride = meta["size"], meta["steps"], meta["lattice_stride"]
+    fac = yk_factory("3axis")
+    soln = fac.new_solution(fac.new_env())
+    soln.set_overall_domain_size_vec(list(g))
+    soln.prepare_solution()
+    init = O.DEFAULT_INIT["3axis"]
+    for v in soln.get_vars():
+        v.set_elements_hash(*init[v.get_name()], hash_id=O.VAR_IDS["3axis"][v.get_name()])
+    soln.run_solution(0, steps - 1)
+    print("kernel:", soln.get_kernel_variant(0))
+    lat = [O.lattice(s, stride) for s in g]
+    var = soln.get_var("A")
+    got = np.stack([var.get_elements_in_slice([steps, int(x), 0, 0], [steps, int(x), g[1] - 1, g[2] - 1])[0][0][np.ix_(lat[1], lat[2])] for x in lat[0]])
+    ref = np.load(G / "c3_3axis_fp64_1024_s4_lattice.npz")[f"A@{steps}"]
+    assert got.shape == ref.shape
+    assert np.abs(got.astype(np.float64) - ref).max() / max(1.0, np.abs(ref).max()) <= 1e-12
+    soln.end_solution()
+

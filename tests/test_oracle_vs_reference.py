@@ -108,6 +108,31 @@ def test_hash_is_layout_independent():
     assert -1.0 <= O.hash_unit(0, 0, 0, 0, 0) < 1.0
 
 
+def _common_points(big, small, reach):
+    """lattice points of two fixtures of the same problem on different grids that lie further than `reach` from the smaller grid's
+    high boundaries: index lists into both arrays"""
+    ma, mb = INDEX[big], INDEX[small]
+    la = [O.lattice(n, ma["lattice_stride"], ma["lattice_edge"]) for n in ma["size"]]
+    lb = [O.lattice(n, mb["lattice_stride"], mb["lattice_edge"]) for n in mb["size"]]
+    ia, ib = [], []
+    for d in range(3):
+        common = [int(v) for v in lb[d] if v < mb["size"][d] - reach and v in set(la[d].tolist())]
+        ia.append([int(np.where(la[d] == v)[0][0]) for v in common])
+        ib.append([int(np.where(lb[d] == v)[0][0]) for v in common])
+    return ia, ib
+
+
+def test_c3_1024_fixture_agrees_with_the_512_fixture_where_both_see_the_same_data():
+    """3axis fp64 at 1024^3 (where the runtime picks its large-grid tile; fixture made at the end of round 3; the C oracle agrees
+    with it to 3.8e-16 on the lattice, a 5-minute / 26 GB check not repeated here) against the 512^3 one: bit for bit on the
+    common points, as for the iso3dfd pair below."""
+    a = np.load(G / "c3_3axis_fp64_1024_s4_lattice.npz")["A@4"]
+    b = np.load(G / "c3_3axis_fp64_512_s4_lattice.npz")["A@4"]
+    ia, ib = _common_points("c3_3axis_fp64_1024_s4_lattice", "c3_3axis_fp64_512_s4_lattice", reach=4 * 4)
+    A, B = a[np.ix_(*ia)], b[np.ix_(*ib)]
+    assert A.size >= 20 ** 3 and np.array_equal(A, B)
+
+
 def test_c4_global_grid_fixture_agrees_with_the_c2_fixture_where_both_see_the_same_data():
     """The 2048 x 2048 x 1024 fixture (BASELINE config 4's global grid, 53 GB in the reference; ref_driver -lattice) and the 1024^3
     one are two runs of the unmodified reference on index-hashed inputs: every lattice point further than steps x radius from the
