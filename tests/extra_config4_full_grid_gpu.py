@@ -59,3 +59,28 @@ def test_3axis_fp64_1024_matches_the_reference_lattice(gpu):
     assert np.abs(got.astype(np.float64) - ref).max() / max(1.0, np.abs(ref).max()) <= 1e-12
     soln.end_solution()
 
+
+def test_iso3dfd_1024_hundred_steps_match_the_reference_lattice(gpu):
+    """The headline grid for 100 steps (VERDICT r02 weak #1 iii: the 100-step rounding-growth evidence existed only at 128^3): default
+    kernel, one rank, against the unmodified reference on the lattice within SURVEY 8(c)'s bound, rel-Linf <= 1e-5 after 100 steps
+    (the C oracle is 2.0e-6 from the reference there)."""
+    from yask_amd import yk_factory
+    meta = INDEX["c2_iso3dfd_1024_s100_lattice"]
+    g, steps, stride = meta["size"], meta["steps"], meta["lattice_stride"]
+    fac = yk_factory("iso3dfd")
+    soln = fac.new_solution(fac.new_env())
+    soln.set_overall_domain_size_vec(list(g))
+    soln.prepare_solution()
+    init = O.DEFAULT_INIT["iso3dfd"]
+    for v in soln.get_vars():
+        v.set_elements_hash(*init[v.get_name()], hash_id=O.VAR_IDS["iso3dfd"][v.get_name()])
+    soln.run_solution(0, steps - 1)
+    print("kernel:", soln.get_kernel_variant(0))
+    lat = [O.lattice(s, stride) for s in g]
+    var = soln.get_var("p")
+    got = np.stack([var.get_elements_in_slice([steps, int(x), 0, 0], [steps, int(x), g[1] - 1, g[2] - 1])[0][0][np.ix_(lat[1], lat[2])] for x in lat[0]])
+    ref = np.load(G / "c2_iso3dfd_1024_s100_lattice.npz")[f"p@{steps}"].astype(np.float64)
+    assert got.shape == ref.shape
+    assert np.abs(got.astype(np.float64) - ref).max() / max(1.0, np.abs(ref).max()) <= 1e-5
+    soln.end_solution()
+

@@ -105,6 +105,8 @@ BIG_CASES = [
     ("c5_ssg_256_s3_lattice", "ssg", "ssg", (256, 256, 256), 3, 16, None),
     # round 3 (VERDICT r02 weak #1 ii): ssg at the size bench.py runs it at, where the kernel shapes are chosen by size
     ("c5_ssg_512_s3_lattice", "ssg", "ssg", (512, 512, 512), 3, 32, None),
+    # late round 3 (VERDICT r02 weak #1 iii): the headline grid for 100 steps -- rounding growth at the full size, not only at 128^3
+    ("c2_iso3dfd_1024_s100_lattice", "iso3dfd", "iso3dfd", (1024, 1024, 1024), 100, 32, ["p"], "driver_lattice"),
     # late round 3: 3axis fp64 at the size bench.py also runs it at -- from 768^3 up the runtime picks the 128 x 32 tile
     ("c3_3axis_fp64_1024_s4_lattice", "3axis_fp64", "3axis", (1024, 1024, 1024), 4, 32, ["A"], "driver_lattice"),
     # late round 3: BASELINE config 4's GLOBAL grid (2048 x 2048 x 1024 = the 8-GPU job).  53 GB in the reference: the driver
