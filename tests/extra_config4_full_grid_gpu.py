@@ -84,3 +84,30 @@ def test_iso3dfd_1024_hundred_steps_match_the_reference_lattice(gpu):
     assert np.abs(got.astype(np.float64) - ref).max() / max(1.0, np.abs(ref).max()) <= 1e-5
     soln.end_solution()
 
+
+def test_heat3d_radius1_matches_the_reference(gpu):
+    """BASELINE config 3 read as the classic 7-point heat3d (the reference's AxisStencil built with -radius 1; library `3axis_r1`):
+    against the unmodified reference -- the small fixture at every point and step, 512^3 on the lattice (<= 1e-12).  Until these
+    fixtures existed the radius-1 library was checked against the C oracle only (which the CPU suite now pins to the same fixtures)."""
+    from yask_amd import yk_factory
+    for name in ("3axis_r1_fp64_24x28x32_s4", "c3_3axis_r1_fp64_512_s4_lattice"):
+        meta = INDEX[name]
+        assert meta["radius"] == 1
+        g, steps = meta["size"], meta["steps"]
+        fac = yk_factory("3axis_r1")
+        soln = fac.new_solution(fac.new_env())
+        soln.set_overall_domain_size_vec(list(g))
+        soln.prepare_solution()
+        A = soln.get_var("A")
+        A.set_elements_hash(*O.DEFAULT_INIT["3axis"]["A"], hash_id=O.VAR_IDS["3axis"]["A"])
+        soln.run_solution(0, steps - 1)
+        z = np.load(G / f"{name}.npz")
+        got = A.get_elements_in_slice([steps, 0, 0, 0], [steps, g[0] - 1, g[1] - 1, g[2] - 1])[0]
+        if "lattice_stride" in meta:
+            lat = [O.lattice(s, meta["lattice_stride"], meta["lattice_edge"]) for s in g]
+            got = got[np.ix_(*lat)]
+        ref = z[f"A@{steps}"]
+        assert got.shape == ref.shape
+        assert np.abs(got.astype(np.float64) - ref).max() / max(1.0, np.abs(ref).max()) <= 1e-12, name
+        soln.end_solution()
+

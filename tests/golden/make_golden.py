@@ -28,6 +28,9 @@ CASES = [
     ("iso3dfd_20x52x36_s5", "iso3dfd", "iso3dfd", (20, 52, 36), 5),
     ("3axis_fp64_24x28x32_s4", "3axis_fp64", "3axis", (24, 28, 32), 4),
     ("ssg_24x20x28_s3", "ssg", "ssg", (24, 20, 28), 3),
+    # BASELINE config 3 calls its fp64 case "heat3d": the classic 7-point stencil is the reference's AxisStencil at -radius 1
+    # (oracle/Makefile ref-kernel STENCIL=3axis TAG=3axis_r1_fp64 REAL_BYTES=8 RADIUS=1); index entries carry "radius": 1
+    ("3axis_r1_fp64_24x28x32_s4", "3axis_r1_fp64", "3axis", (24, 28, 32), 4),
 ]
 
 
@@ -107,6 +110,8 @@ BIG_CASES = [
     ("c5_ssg_512_s3_lattice", "ssg", "ssg", (512, 512, 512), 3, 32, None),
     # late round 3 (VERDICT r02 weak #1 iii): the headline grid for 100 steps -- rounding growth at the full size, not only at 128^3
     ("c2_iso3dfd_1024_s100_lattice", "iso3dfd", "iso3dfd", (1024, 1024, 1024), 100, 32, ["p"], "driver_lattice"),
+    # late round 3: the heat3d reading of config 3 (radius 1) at 512^3
+    ("c3_3axis_r1_fp64_512_s4_lattice", "3axis_r1_fp64", "3axis", (512, 512, 512), 4, 16, ["A"]),
     # late round 3: 3axis fp64 at the size bench.py also runs it at -- from 768^3 up the runtime picks the 128 x 32 tile
     ("c3_3axis_fp64_1024_s4_lattice", "3axis_fp64", "3axis", (1024, 1024, 1024), 4, 32, ["A"], "driver_lattice"),
     # late round 3: BASELINE config 4's GLOBAL grid (2048 x 2048 x 1024 = the 8-GPU job).  53 GB in the reference: the driver
@@ -154,6 +159,8 @@ def main():
         np.savez(HERE / f"{name}.npz", **arrays)
         index[name] = {"stencil": key, "size": list(size), "steps": steps, "arch": arch,
                        "arrays": sorted(arrays), "init": O.DEFAULT_INIT[key]}
+        if "_r1_" in tag:
+            index[name]["radius"] = 1
         print("wrote", name, {k: v.shape for k, v in arrays.items()})
     for name, stencil, size, steps, *rest in GENERIC_CASES:
         if only and name not in only:
@@ -207,6 +214,8 @@ def main():
         np.savez(HERE / f"{name}.npz", **arrays)
         index[name] = {"stencil": key, "size": list(size), "steps": steps, "arch": arch, "arrays": sorted(arrays),
                        "init": O.DEFAULT_INIT[key], "lattice_stride": stride, "lattice_edge": 9}
+        if "_r1_" in tag:
+            index[name]["radius"] = 1
         print("wrote", name, {k: v.shape for k, v in arrays.items()})
     if only:       # partial regeneration: keep the other entries
         old = json.load(open(HERE / "index.json"))

@@ -38,7 +38,8 @@ def test_iso3dfd_matches_reference(name):
 @pytest.mark.parametrize("name", [n for n in INDEX if INDEX[n]["stencil"] == "3axis" and "lattice_stride" not in INDEX[n]])
 def test_axis3_matches_reference(name):
     meta, ref = INDEX[name], _load(name)
-    mine = O.run_axis3(tuple(meta["size"]), meta["steps"], radius=4, dtype=np.float64)
+    # ("radius": 1 = the classic 7-point heat3d, the reference's AxisStencil built with -radius 1; default radius 4)
+    mine = O.run_axis3(tuple(meta["size"]), meta["steps"], radius=meta.get("radius", 4), dtype=np.float64)
     for k, r in ref.items():
         assert O.rel_linf(mine[k], r) <= 1e-13, (k, O.rel_linf(mine[k], r))
 
@@ -75,6 +76,16 @@ def test_c3_3axis_fp64_512_matches_reference_lattice():
     ref = np.load(G / "c3_3axis_fp64_512_s4_lattice.npz")["A@4"]
     mine = _lattice(O.run_axis3(tuple(meta["size"]), meta["steps"])[("A", 4)], meta)
     assert mine.shape == ref.shape and O.rel_linf(mine, ref) <= 1e-13, O.rel_linf(mine, ref)
+
+
+def test_c3_heat3d_radius1_fp64_512_matches_reference_lattice():
+    """BASELINE config 3 read as the classic 7-point heat3d (AxisStencil at radius 1): the C restatement against the unmodified
+    reference built with -radius 1, at 512^3 on the lattice."""
+    meta = INDEX["c3_3axis_r1_fp64_512_s4_lattice"]
+    assert meta["radius"] == 1
+    ref = np.load(G / "c3_3axis_r1_fp64_512_s4_lattice.npz")["A@4"]
+    mine = _lattice(O.run_axis3(tuple(meta["size"]), meta["steps"], radius=1)[("A", 4)], meta)
+    assert mine.shape == ref.shape and O.rel_linf(mine, ref) <= 1e-13
 
 
 def test_c5_ssg_256_matches_reference_lattice():
