@@ -111,3 +111,29 @@ def test_heat3d_radius1_matches_the_reference(gpu):
         assert np.abs(got.astype(np.float64) - ref).max() / max(1.0, np.abs(ref).max()) <= 1e-12, name
         soln.end_solution()
 
+
+def test_ssg_768_matches_the_reference_lattice(gpu):
+    """ssg at 768^3 (576 tiles per plane: the x-chunk heuristic cuts for whole rounds of workgroups), default
+    shapes, one rank, all nine fields against the unmodified reference on the lattice (<= 2e-5 of the field's magnitude)."""
+    from yask_amd import yk_factory
+    meta = INDEX["c5_ssg_768_s3_lattice"]
+    g, steps, stride = meta["size"], meta["steps"], meta["lattice_stride"]
+    fac = yk_factory("ssg")
+    soln = fac.new_solution(fac.new_env())
+    soln.set_overall_domain_size_vec(list(g))
+    soln.prepare_solution()
+    init = O.DEFAULT_INIT["ssg"]
+    for v in soln.get_vars():
+        v.set_elements_hash(*init[v.get_name()], hash_id=O.VAR_IDS["ssg"][v.get_name()])
+    soln.run_solution(0, steps - 1)
+    print("kernels:", [soln.get_kernel_variant(p) for p in range(soln.get_num_parts())])
+    lat = [O.lattice(s, stride) for s in g]
+    z = np.load(G / "c5_ssg_768_s3_lattice.npz")
+    for f in O.SSG_FIELDS:
+        var = soln.get_var(f)
+        got = np.stack([var.get_elements_in_slice([steps, int(x), 0, 0], [steps, int(x), g[1] - 1, g[2] - 1])[0][0][np.ix_(lat[1], lat[2])] for x in lat[0]])
+        ref = z[f"{f}@{steps}"].astype(np.float64)
+        assert got.shape == ref.shape
+        assert np.abs(got.astype(np.float64) - ref).max() / np.abs(ref).max() <= 2e-5, f
+    soln.end_solution()
+

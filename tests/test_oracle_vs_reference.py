@@ -144,6 +144,17 @@ def test_c3_1024_fixture_agrees_with_the_512_fixture_where_both_see_the_same_dat
     assert A.size >= 20 ** 3 and np.array_equal(A, B)
 
 
+def test_c5_ssg_768_fixture_agrees_with_the_512_fixture_where_both_see_the_same_data():
+    """ssg at 768^3 (fixture made at the end of round 3: a 576-tile plane, where the launch geometry differs) against the 512^3 one:
+    all nine fields bit for bit on the common points (reach: 3 steps x 2 stages x 4)."""
+    a, b = np.load(G / "c5_ssg_768_s3_lattice.npz"), np.load(G / "c5_ssg_512_s3_lattice.npz")
+    ia, ib = _common_points("c5_ssg_768_s3_lattice", "c5_ssg_512_s3_lattice", reach=32)
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 9
+    for k in a.files:
+        A, B = a[k][np.ix_(*ia)], b[k][np.ix_(*ib)]
+        assert A.size >= 20 ** 3 and np.array_equal(A, B), k
+
+
 def test_c4_global_grid_fixture_agrees_with_the_c2_fixture_where_both_see_the_same_data():
     """The 2048 x 2048 x 1024 fixture (BASELINE config 4's global grid, 53 GB in the reference; ref_driver -lattice) and the 1024^3
     one are two runs of the unmodified reference on index-hashed inputs: every lattice point further than steps x radius from the
