@@ -1,8 +1,11 @@
-"""BASELINE.json configs[3] at its full size -- NOT collected by the default `pytest tests` run (the file name does not match
-test_*.py): the reference fixture (53 GB on the CPU) was generated at the very end of round 3, after the round's GPU budget was spent,
-so this has yet to run on a GPU once.  Run it with
-    python -m pytest tests/extra_config4_full_grid_gpu.py -m gpu -q
-(eight processes x 8.3 GB on one GPU, about a minute) and, when green, rename it to test_config4_full_grid_gpu.py."""
+"""GPU tests against reference fixtures that were generated at the very end of round 3, AFTER the round's GPU budget was spent -- on
+the CPU, with the unmodified reference: BASELINE config 4's global grid (53 GB there), the headline grid for 100 steps, 3axis fp64 at
+1024^3, ssg at 768^3, the radius-1 (heat3d) reading of config 3.  NOT collected by the default `pytest tests` run (the file name
+does not match test_*.py): none of this has run on a GPU yet.  Run it with
+    python -m pytest tests/extra_big_fixtures_gpu.py -m gpu -q
+(the config-4 cases: eight processes x 8.3 GB on one GPU, about a minute each) and, when green, rename it to test_big_fixtures_gpu.py.
+The fixtures themselves are cross-checked on the CPU (tests/test_oracle_vs_reference.py: bit-identical to the smaller fixtures of the
+same problems wherever both see the same data; the C oracle against them where that is affordable)."""
 import numpy as np
 import pytest
 
