@@ -331,6 +331,97 @@ def test_two_process_gloo_halo_exchange_equals_single_rank(num_ranks):
     assert np.array_equal(got, ref)
 
 
+def _worker_halves(rank, world, port, g, steps, num_ranks, q):
+    """the pipelined half-exchange schedule between REAL processes: a half's messages are posted (isend / irecv of the cut faces)
+    behind its launch and completed only after the next half has been computed"""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = plan(world, rank, g, num_ranks=num_ranks)
+        ls, ofs = tuple(p.local_size), tuple(p.rank_offset)
+        ids, init = O.VAR_IDS["iso3dfd"], O.DEFAULT_INIT["iso3dfd"]
+        pp = [O.fill(ls, H, ids["p"], s, *init["p"], dtype=np.float32, origin=ofs) for s in (0, 1)]
+        v = O.fill(ls, H, ids["v"], 0, *init["v"], dtype=np.float32, origin=ofs)
+        fn = O.lib().yo_iso3dfd_step_f32
+        q1, q2 = _capi.idx_t(), _capi.idx_t()
+        assert _lib().yk_plan_halves(ls[0], H, C.byref(q1), C.byref(q2)) == 1
+        q1, q2 = q1.value, q2.value
+
+        def launch(t, half):
+            src, dst = pp[t % 2], pp[(t + 1) % 2]
+            for a, b in ([(0, q1), (q2, ls[0])] if half == 0 else [(q1, q2)]):
+                s_sub, d_sub, v_sub = (np.ascontiguousarray(x[a:b + 2 * H]) for x in (src, dst, v))
+                fn(O._ptr(s_sub), O._ptr(d_sub), O._ptr(v_sub), C.c_int64(b - a), C.c_int64(ls[1]), C.c_int64(ls[2]), C.c_int64(H), C.c_int(8))
+                dst[a + H:b + H, H:-H, H:-H] = O.interior(d_sub, H)
+
+        def pieces(o, sending, half):
+            sl = slab(p, o, sending=sending)
+            if sl is None:
+                return []
+            f, sz = sl
+            out4 = (_capi.idx_t * 4)()
+            k = _lib().yk_plan_halves_slab(half, 1 if o[0] != 0 else 0, f[0], sz[0], q1, q2, out4)
+            return [((out4[2 * i], f[1], f[2]), (out4[2 * i + 1], sz[1], sz[2])) for i in range(k)]
+
+        def start(t, half):
+            a = pp[(t + 1) % 2]
+            ops, recvs, keep = [], [], []
+            for nr, o in neighbors(p):
+                for f, sz in pieces(o, True, half):
+                    buf = torch.from_numpy(np.ascontiguousarray(a[tuple(slice(H + f[d], H + f[d] + sz[d]) for d in range(3))]))
+                    keep.append(buf)
+                    ops.append(dist.P2POp(dist.isend, buf, nr))
+                for f, sz in pieces(o, False, half):
+                    rb = torch.empty(tuple(sz), dtype=torch.float32)
+                    ops.append(dist.P2POp(dist.irecv, rb, nr))
+                    recvs.append((f, sz, rb))
+            return (dist.batch_isend_irecv(ops) if ops else [], recvs, a, keep)
+
+        def finish(flight):
+            reqs, recvs, a, _ = flight
+            for w in reqs:
+                w.wait()
+            for f, sz, rb in recvs:
+                a[tuple(slice(H + f[d], H + f[d] + sz[d]) for d in range(3))] = rb.numpy()
+
+        flight = None
+        for t in range(steps):
+            for half in (0, 1):
+                launch(t, half)
+                if flight is not None:
+                    finish(flight)             # the previous half's exchange: the launch above did not wait for it
+                flight = start(t, half)
+        finish(flight)
+        q.put((rank, ofs, ls, O.interior(pp[steps % 2], H).copy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_ranks,g", [((1, 1, 2), (40, 30, 40)), ((1, 2, 1), (36, 40, 30))])
+def test_two_process_gloo_pipelined_half_exchanges_equal_single_rank(num_ranks, g):
+    import torch.multiprocessing as mp
+    steps = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_halves, args=(r, 2, port, g, steps, num_ranks, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    parts = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = O.run_iso3dfd(g, steps)[("p", steps)]
+    got = np.zeros(g, np.float32)
+    for _, o, ls, a in parts:
+        got[o[0]:o[0] + ls[0], o[1]:o[1] + ls[1], o[2]:o[2] + ls[2]] = a
+    assert np.array_equal(got, ref)
+
+
 # ------------------------------------------------------------------ (d) native rank bootstrap: the TCP rendezvous
 def _rdv_worker(rank, world, port, q):
     lib = _capi.load("iso3dfd")        # dlopen only
