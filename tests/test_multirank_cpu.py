@@ -5,6 +5,9 @@ GPU is exported device-free (yk_plan_rank / yk_plan_halo_slab, yask_amd/csrc/ykh
 (c) a real 2-process `gloo` run: each rank owns a sub-box, exchanges the planned halo slabs with
     torch.distributed and steps its box with the oracle; the union must equal the single-rank oracle
     bit-for-bit (same arithmetic, same order, halos carry exactly the neighbour's values).
+(b2)/(c2) the same two for the pipelined half-exchange schedule (-hip_halves): the box stepped in two x-halves, the faces cut by
+    yk_plan_halves / yk_plan_halves_slab, a half's messages completed only after the next half has been computed;
+(d)-(g) the native rendezvous and TCP mesh, the wave-front plan, the planned-launch block lists, the halves' block lists and cuts.
 The data path on the GPUs (pack kernel -> RCCL -> unpack kernel) is covered by tests/test_multirank_gpu.py.
 """
 import ctypes as C
