@@ -255,6 +255,95 @@ def _emulate_iso3dfd_halves(nranks, g, steps, num_ranks, deliver):
     return out
 
 
+def _emulate_ssg_halves(nranks, g, steps, num_ranks, deliver):
+    """The same pipeline for a two-stage solution with in-place fields (ssg: stage 1 updates three velocities from six stresses, stage
+    2 the six stresses from the NEW velocities): half-launches S1-A, S1-B, S2-A, S2-B, S1-A ...; behind each, the exchange of what its
+    stage wrote, cut at the halves' planes.  (Model: every field travels 4 wide on all faces -- the library sends each field's own,
+    narrower halos; the coefficient fields are constant and filled with their halos.)"""
+    HS = 4
+    plans = [plan(nranks, r, g, num_ranks=num_ranks) for r in range(nranks)]
+    ids, init = O.VAR_IDS["ssg"], O.DEFAULT_INIT["ssg"]
+    st, cuts = [], []
+    for p in plans:
+        ls, ofs = tuple(p.local_size), tuple(p.rank_offset)
+        f = {n: O.fill(ls, HS, ids[n], 0, *init[n], dtype=np.float32, origin=ofs) for n in O.SSG_FIELDS}
+        k = {n: O.fill(ls, HS, ids[n], 0, *init[n], dtype=np.float32, origin=ofs) for n in O.SSG_COEFFS}
+        st.append((f, k, ls))
+        q1, q2 = _capi.idx_t(), _capi.idx_t()
+        assert _lib().yk_plan_halves(ls[0], HS, C.byref(q1), C.byref(q2)) == 1
+        cuts.append((q1.value, q2.value))
+    stage_fn = [O.lib().yo_ssg_stage1_f32, O.lib().yo_ssg_stage2_f32]
+    written = [O.SSG_FIELDS[:3], O.SSG_FIELDS[3:]]
+
+    def launch(r, stage, half):
+        (f, k, ls), (q1, q2) = st[r], cuts[r]
+        for a, b in ([(0, q1), (q2, ls[0])] if half == 0 else [(q1, q2)]):
+            fs = {n: np.ascontiguousarray(f[n][a:b + 2 * HS]) for n in O.SSG_FIELDS}
+            ks = {n: np.ascontiguousarray(k[n][a:b + 2 * HS]) for n in O.SSG_COEFFS}
+            fa = (C.c_void_p * 9)(*[fs[n].ctypes.data for n in O.SSG_FIELDS])
+            ka = (C.c_void_p * 4)(*[ks[n].ctypes.data for n in O.SSG_COEFFS])
+            stage_fn[stage](fa, ka, C.c_int64(b - a), C.c_int64(ls[1]), C.c_int64(ls[2]), C.c_int64(HS))
+            for n in written[stage]:
+                f[n][a + HS:b + HS, HS:-HS, HS:-HS] = O.interior(fs[n], HS)
+
+    def pieces(r, o, sending, half):
+        sl = slab(plans[r], o, halo=(HS, HS, HS), sending=sending)
+        if sl is None:
+            return []
+        (f, sz), (q1, q2) = sl, cuts[r]
+        out4 = (_capi.idx_t * 4)()
+        kk = _lib().yk_plan_halves_slab(half, 1 if o[0] != 0 else 0, f[0], sz[0], q1, q2, out4)
+        return [((out4[2 * i], f[1], f[2]), (out4[2 * i + 1], sz[1], sz[2])) for i in range(kk)]
+
+    def collect(stage, half):
+        msgs = {}
+        for r in range(nranks):
+            for nr, o in neighbors(plans[r]):
+                msgs[(r, nr)] = [[st[r][0][n][tuple(slice(HS + f[d], HS + f[d] + sz[d]) for d in range(3))].copy() for n in written[stage]]
+                                 for f, sz in pieces(r, o, True, half)]
+        return (stage, half, msgs)
+
+    def land(flight):
+        stage, half, msgs = flight
+        for r in range(nranks):
+            for nr, o in neighbors(plans[r]):
+                got, mine = msgs[(nr, r)], pieces(r, o, False, half)
+                assert len(got) == len(mine)
+                for per_field, (f, sz) in zip(got, mine):
+                    for n, m in zip(written[stage], per_field):
+                        assert m.shape == tuple(sz)
+                        st[r][0][n][tuple(slice(HS + f[d], HS + f[d] + sz[d]) for d in range(3))] = m
+
+    flight = None
+    for _ in range(steps):
+        for stage in (0, 1):
+            for half in (0, 1):
+                if flight is not None and deliver == "early":
+                    land(flight); flight = None
+                for r in range(nranks):
+                    launch(r, stage, half)
+                if flight is not None:
+                    land(flight)
+                flight = collect(stage, half)
+    land(flight)
+    out = {n: np.zeros(g, np.float32) for n in O.SSG_FIELDS}
+    for p, (f, k, ls) in zip(plans, st):
+        o = tuple(p.rank_offset)
+        for n in O.SSG_FIELDS:
+            out[n][o[0]:o[0] + ls[0], o[1]:o[1] + ls[1], o[2]:o[2] + ls[2]] = O.interior(f[n], HS)
+    return out
+
+
+@pytest.mark.parametrize("deliver", ["late", "early"])
+@pytest.mark.parametrize("nranks,num_ranks,g", [(8, (2, 2, 2), (40, 28, 36)), (4, (1, 2, 2), (24, 28, 36))])
+def test_emulated_pipelined_half_exchanges_two_stages_in_place(nranks, num_ranks, g, deliver):
+    steps = 2
+    ref = O.run_ssg(g, steps)
+    got = _emulate_ssg_halves(nranks, g, steps, num_ranks, deliver)
+    for n in O.SSG_FIELDS:
+        assert np.array_equal(got[n], ref[(n, steps)]), n
+
+
 @pytest.mark.parametrize("deliver", ["late", "early"])
 @pytest.mark.parametrize("nranks,num_ranks,g", [(8, (2, 2, 2), (64, 36, 44)), (4, (1, 2, 2), (40, 36, 44)), (4, (2, 2, 1), (70, 36, 30))])
 def test_emulated_pipelined_half_exchanges_equal_single_rank(nranks, num_ranks, g, deliver):
