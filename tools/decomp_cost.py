@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--configs", default="", help="only the configurations whose label contains this text (comma-separated alternatives)")
     ap.add_argument("--cases", type=int, default=99, help="only the first N cases")
+    ap.add_argument("--passes", type=int, default=2, help="interleaved passes over the configurations that share a solution")
+    ap.add_argument("--fresh-solutions", action="store_true", help="one solution (one set of allocations) per configuration, as before round 3's end")
     args = ap.parse_args()
     from yask_amd import yk_factory
     from yask_amd.kernel import yk_env
@@ -62,30 +64,60 @@ def main():
         configs = [c for c in configs if any(k in c[0] for k in args.configs.split(","))]
     cases = cases[:args.cases]
     out = []
-    ramped = False
+    ramped = [False]
+
+    def make(size, opts):
+        s = fac.new_solution(fac.new_env())
+        s.set_overall_domain_size_vec(list(size))
+        assert s.apply_command_line_options("-no-auto_tune " + opts) == ""
+        s.prepare_solution()
+        if not ramped[0]:          # a box that idled is at low clocks: ~1.5 s of plain steps before the first measurement
+            import time
+            t0, t = time.perf_counter(), 0
+            while time.perf_counter() - t0 < 1.5:
+                s.run_solution(t, t + 19)
+                t += 20
+            ramped[0] = True
+        for k, v in enumerate(s.get_vars()):
+            v.set_elements_hash(1.0, 0.1, hash_id=k)
+        return s
+
+    # Every schedule option is a run-time toggle (plans are rebuilt, nothing is re-allocated), so by default ALL configurations of a
+    # case are timed on ONE solution, i.e. on one set of var allocations, in --passes interleaved passes: where the arrays happen to
+    # lie is worth 3-4 % of a step -- more than what some of these schedules differ by (profiles/r3_halves: the
+    # "undivided" column of one case read 0.403 / 0.431 / 0.439 ms on three solutions).  Configurations that change the allocation
+    # (-Mbt with -hip_wf_ext_always) get their own solution; --fresh-solutions restores one solution per configuration.
+    def own_solution(opts):
+        return args.fresh_solutions or "-Mbt" in opts or "-hip_wf_ext_always" in opts
+
     for name, size, lo, hi in cases:
-        for label, opts in configs:
-            s = fac.new_solution(fac.new_env())
-            s.set_overall_domain_size_vec(list(size))
-            assert s.apply_command_line_options("-no-auto_tune " + opts) == ""
-            s.prepare_solution()
-            if not ramped:          # a box that idled is at low clocks: ~1.5 s of plain steps before the first measurement
-                import time
-                t0, t = time.perf_counter(), 0
-                while time.perf_counter() - t0 < 1.5:
-                    s.run_solution(t, t + 19)
-                    t += 20
-                ramped = True
-            for k, v in enumerate(s.get_vars()):
-                v.set_elements_hash(1.0, 0.1, hash_id=k)
-            ext, inter, whole = s.time_decomposed_step(lo, hi, reps=args.reps)
-            pts = size[0] * size[1] * size[2]
-            rec = {"case": name, "config": label, "shell_or_exterior_ms": round(ext, 4), "rest_or_interior_ms": round(inter, 4), "undivided_ms": round(whole, 4),
-                   "overhead": round((ext + inter) / whole, 3), "shell_done_at_fraction": round(ext / (ext + inter), 3),
-                   "gpoints_per_s_decomposed": round(pts / (ext + inter) * 1e-6, 1), "gpoints_per_s_undivided": round(pts / whole * 1e-6, 1)}
-            out.append(rec)
-            print(json.dumps(rec), flush=True)
-            s.end_solution()
+        shared = None
+        for pass_no in range(max(1, args.passes)):
+            for label, opts in configs:
+                own = own_solution(opts)
+                if own and pass_no > 0:
+                    continue
+                if own:
+                    s = make(size, opts)
+                else:
+                    if shared is None:
+                        shared = make(size, "")
+                    s = shared
+                    assert s.apply_command_line_options("-no-auto_tune " + opts) == ""
+                    for k, v in enumerate(s.get_vars()):
+                        v.set_elements_hash(1.0, 0.1, hash_id=k)
+                ext, inter, whole = s.time_decomposed_step(lo, hi, reps=args.reps)
+                pts = size[0] * size[1] * size[2]
+                rec = {"case": name, "config": label, "shell_or_exterior_ms": round(ext, 4), "rest_or_interior_ms": round(inter, 4), "undivided_ms": round(whole, 4),
+                       "overhead": round((ext + inter) / whole, 3), "shell_done_at_fraction": round(ext / (ext + inter), 3),
+                       "gpoints_per_s_decomposed": round(pts / (ext + inter) * 1e-6, 1), "gpoints_per_s_undivided": round(pts / whole * 1e-6, 1),
+                       "solution": "own" if own else "shared by the case's configurations", "pass": pass_no}
+                out.append(rec)
+                print(json.dumps(rec), flush=True)
+                if own:
+                    s.end_solution()
+        if shared is not None:
+            shared.end_solution()
     od = Path(__file__).resolve().parents[1] / "gpurun_out"
     od.mkdir(exist_ok=True)
     json.dump(out, open(od / f"decomp_cost_{args.stencil}.json", "w"), indent=1)

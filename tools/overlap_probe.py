@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--cases", type=int, default=99, help="only the first N cases")
     ap.add_argument("--schedules", default="", help="only the schedules whose label contains this text (comma-separated alternatives)")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--passes", type=int, default=2, help="interleaved passes over the schedules (they share one solution)")
+    ap.add_argument("--fresh-solutions", action="store_true", help="one env + solution per schedule (one pass)")
     ap.add_argument("--grid-study", action="store_true", help="iso3dfd: the 8-GPU rank grids of GRID_CASES instead of the default cases")
     args = ap.parse_args()
     from yask_amd import yk_factory
@@ -73,21 +75,41 @@ def main():
         s.run_solution(10, 10 + args.steps - 1)
         one_ms = (time.perf_counter() - t0) / args.steps * 1e3
         s.end_solution()
-        for label, opts in [x for x in SCHEDULES if any(k in x[0] for k in args.schedules.split(","))]:
+        # Every schedule is a set of run-time options, so by default all schedules of a case run on ONE env + solution, i.e. on one
+        # set of var allocations, in --passes interleaved passes (where the arrays lie is worth 3-4 % of a step, DESIGN.md section 2:
+        # more than some schedules differ by); --fresh-solutions = one solution per schedule, as before the end of round 3.
+        RESET = "-overlap_comms -hip_planned_launch -no-hip_halves -no-hip_inline_pack -hip_planned_split -hip_shell_pct 55 "
+
+        def make(opts):
             env = fac.new_env()
             env.init_mirror(rank, world)
-            s = fac.new_solution(env)
-            s.set_overall_domain_size_vec(list(g))
-            s.set_num_ranks_vec(list(nr))
-            assert s.apply_command_line_options("-no-auto_tune " + opts) == ""
-            s.prepare_solution()
-            for k, v in enumerate(s.get_vars()):
+            so = fac.new_solution(env)
+            so.set_overall_domain_size_vec(list(g))
+            so.set_num_ranks_vec(list(nr))
+            assert so.apply_command_line_options("-no-auto_tune " + opts) == ""
+            so.prepare_solution()
+            for k, v in enumerate(so.get_vars()):
                 v.set_elements_hash(1.0, 0.1, hash_id=k)
-            s.run_solution(0, 9)
+            return so
+
+        chosen = [x for x in SCHEDULES if any(k in x[0] for k in args.schedules.split(","))]
+        shared, t_next = None, 0
+        for pass_no, (label, opts) in [(p_, x) for p_ in range(1 if args.fresh_solutions else max(1, args.passes)) for x in chosen]:
+            if args.fresh_solutions:
+                s, t_next = make(opts), 0
+            else:
+                if shared is None:
+                    shared = make(RESET)
+                s = shared
+                assert s.apply_command_line_options(RESET + opts) == ""
+                for k, v in enumerate(s.get_vars()):         # (fresh values: the test coefficients make the scheme grow without bound)
+                    v.set_elements_hash(1.0, 0.1, hash_id=k)
+            s.run_solution(t_next, t_next + 9)
             s.get_stats()
             t0 = time.perf_counter()
-            s.run_solution(10, 10 + args.steps - 1)
+            s.run_solution(t_next + 10, t_next + 10 + args.steps - 1)
             ms = (time.perf_counter() - t0) / args.steps * 1e3
+            t_next += 10 + args.steps
             st = s.get_stats()
             n = args.steps
             comm = st.get_halo_pack_secs() + st.get_halo_xfer_secs() + st.get_halo_unpack_secs()
@@ -98,10 +120,14 @@ def main():
                    "unpack_ms": round(st.get_halo_unpack_secs() / n * 1e3, 4), "exposed_wait_ms": round(st.get_halo_wait_secs() / n * 1e3, 4),
                    "comm_hidden_fraction": round(max(0.0, 1.0 - st.get_halo_wait_secs() / comm), 3) if comm > 0 else None,
                    "halo_MB_per_step": round(st.get_halo_bytes_sent() / n / 1e6, 2), "rank_grid": list(nr), "rank": rank,
-                   "job_gpoints_per_s_at_8_ranks": round(g[0] * g[1] * g[2] / ms * 1e-6, 1)}
+                   "job_gpoints_per_s_at_8_ranks": round(g[0] * g[1] * g[2] / ms * 1e-6, 1),
+                   "solution": "own" if args.fresh_solutions else "shared by the case's schedules", "pass": pass_no}
             out.append(rec)
             print(json.dumps(rec), flush=True)
-            s.end_solution()
+            if args.fresh_solutions:
+                s.end_solution()
+        if shared is not None:
+            shared.end_solution()
     od = Path(__file__).resolve().parents[1] / "gpurun_out"
     od.mkdir(exist_ok=True)
     json.dump(out, open(od / f"overlap_probe_{args.stencil}{args.tag}.json", "w"), indent=1)
