@@ -119,6 +119,9 @@ BIG_CASES = [
     # late round 3: BASELINE config 4's GLOBAL grid (2048 x 2048 x 1024 = the 8-GPU job).  53 GB in the reference: the driver
     # initialises slab by slab and writes the lattice sample itself (ref_driver -lattice), nothing exists twice in memory
     ("c4_iso3dfd_2048x2048x1024_s2_lattice", "iso3dfd", "iso3dfd", (2048, 2048, 1024), 2, 32, ["p"], "driver_lattice"),
+    # round 4: ssg for 20 steps -- pins the DEFAULT arithmetic of the ssg kernels (reciprocal-based
+    # divisions, -hip_fast_div) against the reference itself over a run long enough for the difference to grow
+    ("c5_ssg_256_s20_lattice", "ssg", "ssg", (256, 256, 256), 20, 16, None),
 ]
 
 
