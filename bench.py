@@ -310,6 +310,9 @@ def main():
                          "then the exchange (-no-overlap_comms).  auto (default): every candidate runs a few steps during warm-up, "
                          "the fastest (max over ranks) is used for the timed region and all timings are reported")
     ap.add_argument("--opts", default="", help="extra yask options, e.g. '-hip_variant NAME'")
+    ap.add_argument("--no-self-check", action="store_true",
+                    help="N>1: skip the parity check every halo transport must pass before it is timed (a small grid on the job's rank grid, three "
+                         "step schedules, gathered on rank 0 and compared bit for bit with a one-rank run; reported as config.self_check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the streaming-bandwidth probe of this box")
     ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "none"],
@@ -375,6 +378,17 @@ def main():
             so.get_var(name).set_elements_hash(off, sc, hash_id=hid)
         return env_, so, used
 
+    # ---- N>1: every halo transport proves itself before it is timed: a small global grid on THIS job's rank grid
+    # and devices, each of the three ways a decomposed step is issued, gathered on rank 0 and compared BIT FOR BIT with a one-rank run
+    # of the same kernel on rank 0's device.  A transport that fails is not used; with no transport left the job is an error.
+    CHECK_KERNEL = {"iso3dfd": "-hip_variant starlin_v4_z128_y16_r1_m_nt_w2_c4 -no-hip_thin_slab_point_kernel",
+                    "ssg": "-hip_variant march_v2_z128_y8_w2 -no-hip_thin_slab_point_kernel",
+                    "3axis": "-hip_variant starlin_v2_z64_y32_r2_u_nt_tl_w2_c4 -no-hip_thin_slab_point_kernel",
+                    "3axis_r1": "-hip_variant starlin_v2_z128_y32_r4_m_nt_w2_c4 -no-hip_thin_slab_point_kernel"}
+    CHECK_SCHEDULES = {"serial": "-no-overlap_comms -no-hip_halves", "planned": "-overlap_comms -hip_planned_launch -no-hip_halves",
+                       "halves": "-overlap_comms -hip_planned_launch -hip_halves"}
+    self_check = {"transports": {}, "devices": None, "what": "small grid on this job's rank grid: every rank's box vs a one-rank run, bit for bit"} if world > 1 and not args.no_self_check else None
+
     def agree_min_int(x):
         if world <= 1:
             return x
@@ -382,41 +396,118 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MIN)
         return int(tt.item())
 
+    def run_self_check(env_, grid_, name):
+        import numpy as np
+        steps_c = 3
+        gsz = [(96 if d == 0 else 48) * grid_[d] if d < 2 else 64 * grid_[d] for d in range(3)]
+        fields = [nm for nm, (off, sc, hid) in init.items() if nm not in ("v", "rho", "mu", "lambda", "lambdamu2")]
+        rec = {"ok": False, "grid": gsz, "steps": steps_c, "schedules": {}}
+        all_ok = True
+        for sched, opt in CHECK_SCHEDULES.items():
+            ok, boxes = 1, None
+            try:
+                so = fac.new_solution(env_)
+                so.set_overall_domain_size_vec(gsz)
+                so.set_num_ranks_vec(list(grid_))
+                assert so.apply_command_line_options(CHECK_KERNEL[stencil] + " " + opt) == ""
+                so.prepare_solution()
+                for nm, (off, sc, hid) in init.items():
+                    so.get_var(nm).set_elements_hash(off, sc, hash_id=hid)
+                so.run_solution(0, steps_c - 1)
+                f, l = so.get_first_rank_domain_index_vec(), so.get_last_rank_domain_index_vec()
+                boxes = (f, l, {nm: so.get_var(nm).get_elements_in_slice([steps_c] + f, [steps_c] + l)[0] for nm in fields})
+                so.end_solution()
+            except Exception as ex:  # noqa: BLE001
+                print(f"bench[{rank}]: self-check of '{name}' / {sched} failed to run: {ex!r}", file=sys.stderr, flush=True)
+                ok = 0
+            if agree_min_int(ok) == 0:          # (every rank issues the same collectives whether or not it failed locally: ADVICE r03)
+                rec["schedules"][sched] = "failed to run"
+                all_ok = False
+                continue
+            gathered = [None] * world if rank == 0 else None
+            torch.distributed.gather_object(boxes, gathered, dst=0)
+            same = 1
+            if rank == 0:
+                one = fac.new_solution(fac.new_env())
+                one.set_overall_domain_size_vec(gsz)
+                assert one.apply_command_line_options(CHECK_KERNEL[stencil]) == ""
+                one.prepare_solution()
+                for nm, (off, sc, hid) in init.items():
+                    one.get_var(nm).set_elements_hash(off, sc, hash_id=hid)
+                one.run_solution(0, steps_c - 1)
+                for f, l, arrs in gathered:
+                    for nm, a in arrs.items():
+                        ref = one.get_var(nm).get_elements_in_slice([steps_c] + f, [steps_c] + l)[0]
+                        if not np.array_equal(a, ref):
+                            same = 0
+                            print(f"bench: self-check of '{name}' / {sched}: box {f}..{l} of '{nm}' differs from the one-rank run "
+                                  f"(max abs diff {float(np.abs(a.astype(np.float64) - ref).max()):.3e})", file=sys.stderr, flush=True)
+                one.end_solution()
+            same = agree_min_int(same)
+            rec["schedules"][sched] = "bit-identical to one rank" if same else "DIFFERS from one rank"
+            all_ok = all_ok and bool(same)
+        rec["ok"] = all_ok
+        return rec
+
+    def checked(c, e_, s_):
+        """the transport of env e_ passes the self-check (or checks are off); collective"""
+        if self_check is None:
+            return True
+        if self_check["devices"] is None:
+            ids = [None] * world
+            torch.distributed.all_gather_object(ids, e_.get_device_bus_id())
+            self_check["devices"] = len(set(ids))
+        rec = run_self_check(e_, s_.get_num_ranks_vec(), c)
+        self_check["transports"][c] = rec
+        return rec["ok"]
+
     # ---- N>1: the halo transport is chosen by measurement too.  "ipc" = copies into the neighbour's buffers through HIP IPC
     # handles (SDMA over xGMI: no compute units, so the bytes move while a stencil launch owns every CU); "rccl" = grouped
     # ncclSend / ncclRecv kernels.  Which is faster on a given node is a property of the node: each candidate runs 2 untimed + 6
     # timed steps on the default schedule, the times are max-reduced over the ranks, the faster one runs the benchmark and both
-    # numbers are reported.  A candidate that cannot be set up on every rank, or fails its trial, is skipped (and reported).
+    # numbers are reported.  A candidate that cannot be set up on every rank, fails the self-check or its trial, is skipped (and
+    # reported).  Every rank issues the same sequence of collectives whether or not a phase failed locally (ADVICE r03).
     transport_ms = None
     if world > 1 and args.transport == "auto":
         cands = ["ipc", "rccl"] if torch.distributed.get_backend() == "nccl" else ["ipc", "torch"]
         transport_ms, built = {}, {}
-        for c in cands:
-            ok, ms = 1, None
+
+        def phase(c, fn):
+            ok = 1
             try:
-                e_, s_, used_ = build(c)
-                assert s_.apply_command_line_options("-overlap_comms -hip_planned_launch") == ""
-                s_.run_solution(0, 1)
-                torch.cuda.synchronize(); torch.distributed.barrier()
-                w0 = time.perf_counter()
-                s_.run_solution(2, 7)
-                torch.cuda.synchronize(); torch.distributed.barrier()
-                ms = (time.perf_counter() - w0) / 6 * 1e3
-                built[c] = (e_, s_, used_)
+                fn()
+                torch.cuda.synchronize()
             except Exception as ex:  # noqa: BLE001
                 print(f"bench[{rank}]: halo transport '{c}' unusable: {ex!r}", file=sys.stderr, flush=True)
                 ok = 0
-            if agree_min_int(ok) == 0:
-                transport_ms[c] = None
+            return agree_min_int(ok) == 1
+
+        for c in cands:
+            transport_ms[c] = None
+            if not phase(c, lambda: built.__setitem__(c, build(c))):
                 if c in built:
                     built.pop(c)[1].end_solution()
+                continue
+            e_, s_, used_ = built[c]
+            good = checked(c, e_, s_)
+            good = good and phase(c, lambda: (s_.apply_command_line_options("-overlap_comms -hip_planned_launch"), s_.run_solution(0, 1)))
+            if good:
+                torch.distributed.barrier()
+                w0 = time.perf_counter()
+                good = phase(c, lambda: s_.run_solution(2, 7))
+                ms = (time.perf_counter() - w0) / 6 * 1e3
+            if not good:
+                try:
+                    built.pop(c)[1].end_solution()
+                except Exception:  # noqa: BLE001
+                    pass
                 continue
             tt = torch.tensor([ms], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             transport_ms[c] = round(float(tt.item()), 4)
         usable = [c for c in cands if transport_ms.get(c) is not None]
         if not usable:
-            raise SystemExit("bench.py: no halo transport could be set up on every rank")
+            raise SystemExit("bench.py: no halo transport could be set up on every rank and pass its self-check")
         best = min(usable, key=lambda c: transport_ms[c])
         for c in list(built):
             if c != best:
@@ -427,6 +518,8 @@ def main():
             soln.get_var(name).set_elements_hash(off, sc, hash_id=hid)
     else:
         env, soln, transport = build("rccl" if args.transport == "auto" else args.transport)
+        if world > 1 and not checked(transport, env, soln):
+            raise SystemExit(f"bench.py: the '{transport}' halo transport failed its self-check against a one-rank run: {json.dumps(self_check)}")
     local = soln.get_rank_domain_size_vec()
     glob_sz = soln.get_overall_domain_size_vec()
     grid = soln.get_num_ranks_vec()
@@ -562,7 +655,7 @@ def main():
                        "baseline_config": {"c2": "configs[1] (1024^3 global)", "c4": "configs[3] (1024x1024x512 per GPU, compact grid)",
                                            "weak": "one block per GPU"}[args.config] if not args.local else "explicit --points-per-gpu",
                        "decomposition": ("rank grid (--rank-grid) " if args.rank_grid else "x-slabs " if decomp == "xslab" else "compact rank grid ") + "x".join(str(g) for g in grid),
-                       "halo_transport": transport, "transport_trials_ms_per_step": transport_ms,
+                       "halo_transport": transport, "transport_trials_ms_per_step": transport_ms, "self_check": self_check,
                        "kernel": "+".join(soln.get_kernel_variant(p) for p in range(nparts)),
                        "overlap_comms": (schedule != "serial") if world > 1 else None,
                        "schedule": schedule, "schedule_trials_ms_per_step": schedule_ms,

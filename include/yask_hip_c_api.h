@@ -59,12 +59,18 @@ void yk_env_set_trace_enabled(yk_env_h env, int enable); /* yk_env::set_trace_en
 /* Multi-GPU: one process per GPU. The reference takes an MPI communicator (new_env(MPI_Comm), :136);
  * here the host states rank/size and installs a halo transport. */
 int yk_env_set_ranks(yk_env_h env, int rank, int num_ranks);
+/* PCI bus id of the device this process computes on ("0000:05:00.0"; the reference prints the host name of each rank,
+ * setup.cpp:120-135): what a multi-device test asserts differs between the ranks.  Returns the length, < 0 on error. */
+int yk_env_get_device_bus_id(yk_env_h env, char* out, int cap);
 typedef struct {
     int peer;            /* neighbour rank */
     void* send_buf;      /* contiguous device buffers */
     void* recv_buf;
     size_t send_bytes, recv_bytes;
     int tag;
+    int key;    /* which of the receiver's buffers, named alike on both ends: 0 = its packed buffer for this direction,
+                 * (var ordinal * 16 + step slot) + 1 = the planes of that var slot (in-place x faces); plus 4096 x the
+                 * solution's ordinal within its env */
 } yk_halo_msg;
 /* start: enqueue all transfers ordered after prior work on `stream` (a hipStream_t);
  * wait : make later work on `stream` see the received bytes. Return 0 on success. */
@@ -91,6 +97,13 @@ int yk_env_init_tcp(yk_env_h env, int rank, int num_ranks, const char* addr, int
  * MPI requests during the interior (adv_halo_exchange, src/kernel/lib/halo.cpp:494-574).  Ranks may share a device (tests).
  * Control messages and the scalar all-reduce run over the same TCP mesh as yk_env_init_tcp(). YASK_HIP_TRANSPORT=ipc. */
 int yk_env_init_ipc(yk_env_h env, int rank, int num_ranks, const char* addr, int base_port);
+/* Control-plane counters of the installed halo transport (only the IPC transport keeps them; the reference counts its MPI
+ * traffic in yk_stats, context.hpp:319-328): out[0] buffer registrations sent over the TCP mesh, out[1] their bytes -- both
+ * stay flat once every channel has been used once, i.e. the host is out of the loop of an exchange --, out[2] collective
+ * begin calls (one 8-byte all-reduce per run_solution() / exchange_halos() call), out[3] collective resets, out[4] device
+ * operations enqueued (flag kernels + copies), out[5] kind of mailbox memory (0 uncached device, 1 fine-grained device,
+ * 2 plain device -- refused across devices --, 3 pinned host).  Returns how many values it wrote, 0 = no counters. */
+int yk_env_get_transport_counters(yk_env_h env, long long* out, int cap);
 /* Timing instrument, not a transport: this ONE process plays rank `rank` of `num_ranks`; what it sends to a neighbour comes back
  * as what it expects from that neighbour (a device-to-device copy on the communication stream; the halo DATA are therefore those
  * of a reflecting boundary).  Runs the full launch / pack / copy / unpack / wait schedule of a decomposed job's rank on one GPU:

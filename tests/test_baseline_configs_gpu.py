@@ -71,7 +71,7 @@ def test_c1_iso3dfd_128_100_steps_matches_reference(gpu):
     meta = INDEX["c1_iso3dfd_128_s100"]
     ref = np.load(G / "c1_iso3dfd_128_s100.npz")["p@100"]
     n, steps = meta["size"], meta["steps"]
-    for opts in ("", "-hip_variant starlin_v4_z128_y32_r2_t2_nt_pd2_tl_w2_c2", "-hip_variant starlin_v4_z128_y32_r2_t2_nt_pd2_w2_c2"):     # the timed pick, the headline kernel, round 2's
+    for opts in ("", "-hip_variant starlin_v4_z128_y32_r2_t2_nt_pd2_tl_w2_c2", "-hip_variant starlin_v4_z128_y32_r2_t_nt_pd2_tl_w2_c2"):     # the timed pick, the headline kernel, its twin for planned launches
         soln = make("iso3dfd", n, opts)
         soln.run_solution(0, steps - 1)
         p = soln.get_var("p")

@@ -97,3 +97,26 @@ def test_fuse_into_unallocated_source_and_layout_mismatch(gpu):
         c.get_var("p").fuse_vars(make().get_var("p"))
     with pytest.raises(RuntimeError, match="dims"):
         c.get_var("v").fuse_vars(make().get_var("p"))
+
+
+def test_vars_fused_before_prepare_must_end_up_with_one_layout(gpu):
+    """two vars fused while their solutions are still unprepared have no geometry to compare yet; when the
+    solutions then give them different sizes, the one prepared last would re-allocate the SHARED storage with its own byte count
+    and the other would index it with other strides.  The reference requires identical layouts for solution vars
+    (yk_var_apis.cpp:344-351); here the mismatch is caught at the moment it arises, in prepare_solution()."""
+    from yask_amd import yk_factory
+    fac = yk_factory("iso3dfd")
+    a, b = fac.new_solution(fac.new_env()), fac.new_solution(fac.new_env())
+    b.get_var("p").fuse_vars(a.get_var("p"))             # both unprepared: allowed
+    a.set_overall_domain_size_vec(list(SIZE))
+    b.set_overall_domain_size_vec([SIZE[0], SIZE[1] + 16, SIZE[2]])
+    a.prepare_solution()
+    with pytest.raises(RuntimeError, match="layouts"):
+        b.prepare_solution()
+    # the same sizes: fine, and the storage is shared
+    c, d = fac.new_solution(fac.new_env()), fac.new_solution(fac.new_env())
+    d.get_var("p").fuse_vars(c.get_var("p"))
+    for s in (c, d):
+        s.set_overall_domain_size_vec(list(SIZE))
+        s.prepare_solution()
+    assert c.get_var("p").get_device_storage() == d.get_var("p").get_device_storage()

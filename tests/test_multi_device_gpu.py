@@ -1,0 +1,251 @@
+"""Halo exchange ACROSS devices (VERDICT r03 missing #1 / next #1; SURVEY.md section 8 rows a10, e).
+
+Every other multi-rank GPU test of this suite puts its ranks on ONE device, because the test box has one.  These tests need
+`torch.cuda.device_count() >= 2` and skip cleanly otherwise: one process per device (LOCAL_RANK = rank, native bootstrap, no
+torch in the rank processes), the built-in RCCL transport (grouped ncclSend / ncclRecv over xGMI, csrc/ykh_rccl.cpp) and the
+IPC transport (copies into the neighbour's buffers + flag words every device sees coherently, csrc/ykh_ipc.cpp), each with
+the three ways a decomposed step is issued -- exchange after the launch (`-no-overlap_comms`), the planned launch with the
+exchange released from the device, and the pipelined half-exchanges (`-hip_halves`) -- the matrix the reference runs for
+`ranks > 1` with both overlap settings (src/kernel/Makefile:1042-1062, `yk-mpi-tests`; halo.cpp:80-491).
+
+Pass = every rank's box equals the same box of the ONE-rank run bit for bit (128-bit digests of the raw values), the one-rank
+run equals the C oracle within the fp32 tolerance, and nobody hangs: a flag that never arrives fails the IPC waiter after
+YASK_HIP_WAIT_TIMEOUT_S = 15 s with the mailbox state printed, and the parent kills the job 90 s after its start whatever the
+transport.  bench.py's N > 1 flow, with its own self-check against a one-rank run, is driven the same way at the end."""
+import hashlib
+import json
+import os
+import queue
+import socket
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+ROOT = Path(__file__).resolve().parents[1]
+FIELDS = {"iso3dfd": ["p"], "ssg": O.SSG_FIELDS}
+# one kernel everywhere (bit-exactness vs one rank): the shapes the library picks for large boxes, named
+KERNEL = {"iso3dfd": "-hip_variant starlin_v4_z128_y16_r1_m_nt_w2_c4 -no-hip_thin_slab_point_kernel",
+          "ssg": "-hip_variant march_v2_z128_y8_w2 -no-hip_thin_slab_point_kernel"}
+SCHEDULES = {"serial": "-no-overlap_comms", "planned": "-overlap_comms -hip_planned_launch", "halves": "-overlap_comms -hip_halves"}
+WATCHDOG_S = 90
+
+
+def _ndev():
+    try:
+        import torch
+        return torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+# YASK_TEST_MULTI_DEVICE_DRYRUN=1: run this file's logic on a ONE-GPU box (all ranks on device 0; what can work there: the IPC
+# transport, bench.py over gloo) -- so that the tests themselves are known to be sound before a multi-GPU box first sees them
+DRYRUN = os.environ.get("YASK_TEST_MULTI_DEVICE_DRYRUN", "") not in ("", "0")
+REAL_NDEV = _ndev()
+NDEV = 8 if DRYRUN and REAL_NDEV >= 1 else REAL_NDEV
+TRANSPORTS = ["ipc"] if DRYRUN else ["rccl", "ipc"]
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(NDEV < 2, reason=f"needs two or more GPUs in one box, this one has {NDEV}")]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _init(soln, stencil):
+    init = O.DEFAULT_INIT[stencil]
+    for v in soln.get_vars():
+        v.set_elements_hash(*init[v.get_name()], hash_id=O.VAR_IDS[stencil][v.get_name()])
+
+
+def _digests(soln, stencil, t, first, last):
+    out = {}
+    for name in FIELDS[stencil]:
+        var = soln.get_var(name)
+        h = hashlib.blake2b(digest_size=16)
+        for x0 in range(first[0], last[0] + 1, 32):
+            x1 = min(last[0], x0 + 31)
+            h.update(np.ascontiguousarray(var.get_elements_in_slice([t, x0, first[1], first[2]], [t, x1, last[1], last[2]])[0]).tobytes())
+        out[name] = h.hexdigest()
+    return out
+
+
+def _worker(rank, world, port, q, stencil, g, nr, steps, opts, transport):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      YASK_HIP_WAIT_TIMEOUT_S="15", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if transport == "ipc":
+        os.environ["YASK_HIP_TRANSPORT"] = "ipc"
+    else:
+        os.environ.pop("YASK_HIP_TRANSPORT", None)        # the launcher bootstrap's default: RCCL
+    from yask_amd import yk_factory
+    fac = yk_factory(stencil)
+    env = fac.new_env()
+    env.init_from_launcher()                     # binds this process to device LOCAL_RANK, then the transport
+    assert env.get_num_ranks() == world and env.get_rank_index() == rank
+    env.transport_loopback(1 << 16)
+    assert env.sum_over_ranks(rank + 1) == world * (world + 1) // 2
+    soln = fac.new_solution(env)
+    soln.set_overall_domain_size_vec(list(g))
+    soln.set_num_ranks_vec(list(nr))
+    assert soln.apply_command_line_options(KERNEL[stencil] + " " + opts) == ""
+    soln.prepare_solution()
+    _init(soln, stencil)
+    soln.run_solution(0, steps - 2)
+    soln.run_solution(steps - 1, steps - 1)          # a second call: registrations / communicators are re-used
+    f, l = soln.get_first_rank_domain_index_vec(), soln.get_last_rank_domain_index_vec()
+    st = soln.get_stats()
+    info = dict(device=env.get_device_bus_id(), counters=env.get_transport_counters(),
+                msgs=st.get_halo_msgs_sent(), sent=st.get_halo_bytes_sent(), grid=soln.get_num_ranks_vec())
+    q.put((rank, f, l, _digests(soln, stencil, steps, f, l), info))
+    env.global_barrier()
+    soln.end_solution()
+
+
+def _run_ranks(world, stencil, g, nr, steps, opts, transport):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, stencil, g, nr, steps, opts, transport)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts, t0 = [], time.time()
+    while len(parts) < world:
+        try:
+            parts.append(q.get(timeout=1))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > WATCHDOG_S:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                pytest.fail(f"{transport} / {opts or 'default'}: " + ("a rank died" if dead else f"no result after {WATCHDOG_S} s (hung exchange?)") +
+                            f"; exit codes {[p.exitcode for p in procs]} (the ranks' messages, incl. the mailbox dump of the IPC transport, are on stderr)")
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(parts)
+
+
+_ONE = {}
+
+
+def _one_rank(stencil, g, steps):
+    """The one-rank run on device 0 of the parent: the solution is kept for the boxes' digests, and checked against the oracle."""
+    key = (stencil, tuple(g), steps)
+    if key not in _ONE:
+        from yask_amd import yk_factory
+        fac = yk_factory(stencil)
+        one = fac.new_solution(fac.new_env())
+        one.set_overall_domain_size_vec(list(g))
+        assert one.apply_command_line_options(KERNEL[stencil]) == ""
+        one.prepare_solution()
+        _init(one, stencil)
+        one.run_solution(0, steps - 1)
+        ref = O.run_iso3dfd(g, steps) if stencil == "iso3dfd" else O.run_ssg(g, steps)
+        for n in FIELDS[stencil]:
+            got = one.get_var(n).get_elements_in_slice([steps, 0, 0, 0], [steps, g[0] - 1, g[1] - 1, g[2] - 1])[0].astype(np.float64)
+            r = ref[(n, steps)].astype(np.float64)
+            assert np.abs(got - r).max() / max(1.0 if stencil == "iso3dfd" else 1e-30, np.abs(r).max()) <= 2e-5, n
+        _ONE.clear()            # (one at a time: these are not small)
+        _ONE[key] = one
+    return _ONE[key]
+
+
+def _check(parts, stencil, g, nr, steps, transport):
+    one = _one_rank(stencil, g, steps)
+    assert len(parts) == nr[0] * nr[1] * nr[2]
+    for rank, f, l, dig, info in parts:
+        assert info["grid"] == list(nr)
+        assert info["msgs"] > 0 and info["sent"] > 0
+        assert dig == _digests(one, stencil, steps, f, l), f"rank {rank} box {f}..{l} differs from the one-rank run ({transport})"
+        if transport == "ipc":
+            c = info["counters"]
+            assert c["mailbox_kind"] in ((0, 1, 2, 3) if DRYRUN else (0, 1, 3)), c        # never plain (cached) device memory across devices
+            assert c["ctl_bytes"] == 96 * c["ctl_msgs"] and c["begins"] >= 2
+
+
+GRIDS2 = [(2, 1, 1), (1, 1, 2)]
+CASES = [("iso3dfd", (192, 128, 256), 5), ("ssg", (96, 64, 128), 3)]
+
+
+@pytest.mark.parametrize("schedule", list(SCHEDULES))
+@pytest.mark.parametrize("transport", TRANSPORTS)
+@pytest.mark.parametrize("nr", GRIDS2, ids=lambda nr: "x".join(map(str, nr)))
+@pytest.mark.parametrize("stencil,g,steps", CASES, ids=[c[0] for c in CASES])
+def test_two_devices_equal_one_rank(stencil, g, steps, nr, transport, schedule):
+    parts = _run_ranks(2, stencil, g, nr, steps, SCHEDULES[schedule], transport)
+    devs = {info["device"] for *_, info in parts}
+    assert DRYRUN or len(devs) == 2, f"the two ranks sat on one device: {devs}"
+    _check(parts, stencil, g, nr, steps, transport)
+
+
+@pytest.mark.skipif(NDEV < 4, reason="needs four GPUs")
+@pytest.mark.parametrize("transport", TRANSPORTS)
+@pytest.mark.parametrize("nr", [(4, 1, 1), (1, 2, 2)], ids=["4x1x1", "1x2x2"])
+def test_four_devices_equal_one_rank(nr, transport):
+    stencil, g, steps = "iso3dfd", (256, 128, 256), 4
+    _check(_run_ranks(4, stencil, g, nr, steps, SCHEDULES["halves"], transport), stencil, g, nr, steps, transport)
+
+
+@pytest.mark.skipif(NDEV < 8, reason="needs eight GPUs")
+@pytest.mark.parametrize("schedule", list(SCHEDULES))
+@pytest.mark.parametrize("transport", TRANSPORTS)
+@pytest.mark.parametrize("stencil,g,steps", [("iso3dfd", (256, 256, 256), 4), ("ssg", (128, 96, 128), 3)], ids=["iso3dfd", "ssg"])
+def test_eight_devices_on_the_compact_2x2x2_grid(stencil, g, steps, transport, schedule):
+    """BASELINE configs[3] / [4]'s rank grid: three face neighbours per rank (ssg: three edge neighbours too), each on its own link."""
+    _check(_run_ranks(8, stencil, g, (2, 2, 2), steps, SCHEDULES[schedule], transport), stencil, g, (2, 2, 2), steps, transport)
+
+
+@pytest.mark.skipif(DRYRUN, reason="ranks share the device in a dry run: plain memory is allowed there")
+def test_plain_mailbox_is_refused_across_devices():
+    """Flag words that another device polls must not sit in this device's cache."""
+    code = ("import os,sys\n"
+            "from yask_amd import yk_factory\n"
+            "env = yk_factory('iso3dfd').new_env()\n"
+            "try:\n"
+            "    env.init_from_launcher()\n"
+            "except RuntimeError as e:\n"
+            "    print('REFUSED', e); sys.exit(0)\n"
+            "sys.exit(3)\n")
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   YASK_HIP_TRANSPORT="ipc", YASK_HIP_MAILBOX="plain", PYTHONPATH=str(ROOT))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=WATCHDOG_S)
+        assert p.returncode == 0 and "REFUSED" in out, out + err
+        assert "refused when ranks sit on different devices" in err
+
+
+@pytest.mark.parametrize("n", [n for n in (2, 4, 8) if n <= max(NDEV, 2)])
+def test_bench_on_real_devices_with_its_self_check(n):
+    """bench.py as the driver launches it (torch.distributed.run, one rank per device, RCCL process group): both transports set up,
+    each checked against a one-rank run before it may be timed (config.self_check), the faster one kept."""
+    if n > NDEV:
+        pytest.skip(f"needs {n} GPUs")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "2", "--size", "256",
+           "--ramp-secs", "0.2"]
+    env = dict(os.environ, YASK_HIP_WAIT_TIMEOUT_S="15", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if DRYRUN:
+        env["YASK_DIST_BACKEND"] = "gloo"
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == n and j["value"] > 0 and j["scaling"] == "strong"
+    sc = j["config"]["self_check"]
+    assert sc["transports"] and all(v["ok"] for v in sc["transports"].values()), sc
+    assert j["config"]["halo_transport"] in sc["transports"]
+    assert sc["devices"] == (1 if DRYRUN else n)

@@ -1,7 +1,10 @@
 """Drop-in proof for the C++ boundary: the reference's OWN kernel-API test
 programs -- src/kernel/tests/yask_kernel_api_test.cpp and yask_kernel_api_exception_test.cpp, compiled
-UNCHANGED from the reference tree (asserts on) -- linked against libyask_kernel.test_3d.cdna4_hip.so
-through the yk_* adapter (yask_amd/cxxapi/yk_hip_adapter.cpp) must run to completion on the GPU.
+UNCHANGED from the reference tree (asserts on) -- linked against libyask_kernel.test_3d.cdna4_hip.so ALONE (the library
+carries the C++ yk_* API itself: the adapter yask_amd/cxxapi/yk_hip_adapter.cpp over the C ABI is linked into every stencil
+library, as the reference's libyask_kernel.<stencil>.<arch>.so exports yk_factory, src/kernel/Makefile:684-698,
+factory.cpp:36-109) must run to completion on the GPU; and the reference's example APPLICATION src/examples/wave_eq_main.cpp,
+compiled unchanged against the fp64 wave2d library alone, must meet its own L2 tolerance against the analytic solution.
 The executables are produced by `make -C yask_amd/cxxapi` where the reference tree is available
 (__graft_entry__.build() does it in the dev container) and travel with the repo snapshot."""
 import subprocess
@@ -36,3 +39,29 @@ def test_reference_kernel_api_exception_test_program(gpu):
     assert "run_solution() called without calling prepare_solution() first" in out
     assert "called with 4 indices instead of 3 for var 'fvar'" in out
     assert "with buffer of size 800; 1600 needed" in out
+
+
+def test_reference_example_application_wave_eq(gpu):
+    """src/examples/wave_eq_main.cpp (shallow-water standing wave on the `wave2d` solution, real_bytes = 8 as in
+    src/examples/wave_eq.mk): the application builds its own grid, steps it, and compares the elevation with the analytic
+    solution -- `Overall L2 error` must stay below ITS tolerance of 1e-2 (wave_eq_main.cpp:366-415), else it exits non-zero."""
+    r = _run("wave_eq.exe")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    out = r.stdout + r.stderr
+    assert "Overall L2 error:" in out and "SUCCESS" in out, out[-2000:]
+    err = float(out.split("Overall L2 error:")[1].split()[0])
+    assert 0 < err < 1e-2
+
+
+def test_every_hot_path_library_exports_the_cxx_factory():
+    """`nm -D`: yask::yk_factory::new_env / new_solution are defined by the stencil libraries themselves."""
+    lib = B.parents[1] / "lib"
+    for s in ("iso3dfd", "3axis", "ssg", "test_3d", "wave2d_f64"):
+        p = lib / f"libyask_kernel.{s}.cdna4_hip.so"
+        if not p.exists():
+            pytest.skip(f"{p} not built")
+        syms = subprocess.run(["nm", "-D", "--defined-only", "-C", str(p)], capture_output=True, text=True).stdout
+        if "yk_hip_adapter" not in syms and "yask::yk_factory::new_env" not in syms and not (B / "yk_hip_adapter.o").exists():
+            pytest.skip("libraries built without the reference tree: C ABI only")
+        assert "yask::yk_factory::new_env" in syms and "yask::yk_factory::new_solution" in syms, s
+        assert "yk_new_env" in syms        # and the C ABI next to it

@@ -100,12 +100,18 @@ def test_step_alloc_change_reallocates(gpu):
 
 
 # ------------------------------------------------------------------ several ranks, one GPU, native bootstrap + TCP transport
-FIELDS = {"iso3dfd": ["p"], "ssg": O.SSG_FIELDS}
+FIELDS = {"iso3dfd": ["p"], "ssg": O.SSG_FIELDS, "test_boundary_3d": ["A"],
+          "awp_abc": ["vel_x", "vel_y", "vel_z", "stress_xx", "stress_yy", "stress_zz", "stress_xy", "stress_xz", "stress_yz"]}
 KERNEL = {"iso3dfd": "-hip_variant starlin_v4_z128_y16_r1_m_nt_w2_c4 -no-hip_thin_slab_point_kernel",
-          "ssg": "-hip_variant march_v2_z128_y8_w2 -no-hip_thin_slab_point_kernel"}      # one kernel everywhere: bit-exact vs 1 rank
+          "ssg": "-hip_variant march_v2_z128_y8_w2 -no-hip_thin_slab_point_kernel",      # one kernel everywhere: bit-exact vs 1 rank
+          "test_boundary_3d": "-hip_variant naive", "awp_abc": "-hip_variant naive"}      # (sub-domain parts: the point kernel)
 
 
 def _init(soln, stencil):
+    if stencil not in O.DEFAULT_INIT:        # the reference's test stencils: every var hashed, as tests/golden/make_golden.py does
+        for i, v in enumerate(soln.get_vars()):
+            v.set_elements_hash(1.5, 0.5, hash_id=i)
+        return
     init = O.DEFAULT_INIT[stencil]
     for v in soln.get_vars():
         v.set_elements_hash(*init[v.get_name()], hash_id=O.VAR_IDS[stencil][v.get_name()])
@@ -137,6 +143,25 @@ def _tcp_worker(rank, world, port, q, mode, stencil, g, nr, steps):
         soln.exchange_halos()
         q.put((rank, p.get_element([1, f0[0] - 1, 7, 9]) if rank == 1 else None))   # my left halo = rank 0's last plane
         env.global_barrier()
+        return
+    if mode == "counters":
+        # the IPC transport's control plane: registrations travel once per channel, then the host only enqueues device work
+        soln.run_solution(0, steps - 1)
+        c1 = env.get_transport_counters()
+        soln.run_solution(steps, 2 * steps - 1)
+        c2 = env.get_transport_counters()
+        soln.run_solution(2 * steps, 4 * steps - 1)
+        c3 = env.get_transport_counters()
+        # buffers re-made (what the reference's prepare_solution() does to its MPI buffers): every rank re-registers, together
+        soln.prepare_solution()
+        _init(soln, stencil)
+        soln.run_solution(0, steps - 1)
+        c4 = env.get_transport_counters()
+        f, l = soln.get_first_rank_domain_index_vec(), soln.get_last_rank_domain_index_vec()
+        out = {n: soln.get_var(n).get_elements_in_slice([steps] + f, [steps] + l)[0] for n in FIELDS[stencil]}
+        q.put((rank, f, out, dict(c=[c1, c2, c3, c4], grid=soln.get_num_ranks_vec())))
+        env.global_barrier()
+        soln.end_solution()
         return
     soln.run_solution(0, steps - 1)
     st = soln.get_stats()
@@ -191,7 +216,7 @@ def _one_rank(stencil, g, steps):
 
 
 def _assemble(parts, stencil, g):
-    full = {n: np.zeros(g, np.float32) for n in FIELDS[stencil]}
+    full = {n: np.zeros(g, parts[0][2][n].dtype) for n in FIELDS[stencil]}
     for _, f, out, _ in parts:
         for n, a in out.items():
             full[n][f[0]:f[0] + a.shape[0], f[1]:f[1] + a.shape[1], f[2]:f[2] + a.shape[2]] = a
@@ -223,6 +248,33 @@ def test_native_bootstrap_two_ranks_equal_one_rank(gpu, mode, transport, monkeyp
         assert s["xfer"] > 0 and s["inter"] >= 0 and s["ext"] > 0 and s["wait"] >= 0
         assert s["halo"] >= s["pack"] + s["xfer"] + s["unpack"] - 1e-9
         assert s["hidden"] is not None and 0.0 <= s["hidden"] <= 1.0
+
+
+@pytest.mark.parametrize("stencil,g,world,nr,opts", [("iso3dfd", (48, 40, 72), 2, (2, 1, 1), ""), ("iso3dfd", (48, 40, 72), 8, (2, 2, 2), "-hip_halves"),
+                                                    ("ssg", (32, 28, 40), 8, (2, 2, 2), "")])
+def test_ipc_transport_keeps_the_host_out_of_the_exchange(gpu, stencil, g, world, nr, opts, monkeypatch):
+    """the address of a receive buffer crosses the TCP mesh ONCE per channel (first use); after
+    that run_solution() costs one 8-byte all-reduce per CALL and no control message per step or exchange -- counted by the
+    transport itself (yk_env_get_transport_counters).  Re-made buffers (prepare_solution() again) are re-registered by all
+    ranks together, and the result after that still equals the one-rank run bit for bit."""
+    monkeypatch.setenv("YASK_TEST_TRANSPORT", "ipc")
+    monkeypatch.setenv("YASK_TEST_EXTRA_OPTS", opts)
+    steps = 4
+    parts = _run_ranks(world, "counters", stencil=stencil, g=g, nr=nr, steps=steps)
+    for _, _, _, s in parts:
+        c1, c2, c3, c4 = s["c"]
+        assert s["grid"] == list(nr)
+        assert c1["ctl_msgs"] > 0 and c1["ctl_bytes"] == 96 * c1["ctl_msgs"]
+        assert c2["ctl_msgs"] == c1["ctl_msgs"] and c3["ctl_msgs"] == c1["ctl_msgs"], (c1, c2, c3)       # steady state: 0 bytes per step
+        assert c2["begins"] == c1["begins"] + 1 and c3["begins"] == c2["begins"] + 1                      # one all-reduce per call
+        assert c3["resets"] == c1["resets"]
+        assert c3["dev_ops"] - c2["dev_ops"] > c2["dev_ops"] - c1["dev_ops"] > 0                          # device work scales with the steps, only
+        assert c4["resets"] == c3["resets"] + 1 and c4["ctl_msgs"] == 2 * c1["ctl_msgs"]                  # registered again, once
+        assert c1["mailbox_kind"] in (0, 1, 2, 3)
+    full = _assemble(parts, stencil, g)
+    one = _one_rank(stencil, g, steps)
+    for n in FIELDS[stencil]:
+        assert np.array_equal(full[n], one[n]), n
 
 
 @pytest.mark.parametrize("transport", ["tcp", "ipc"])
@@ -337,3 +389,24 @@ def test_wave_front_tiling_across_ranks_halves_the_exchanges(gpu, stencil, g, wo
         assert b["msgs"] >= steps * stages * (3 if world == 8 else 1)
         assert a["msgs"] / n26 < b["msgs"] / (3 if world == 8 else 1)          # fewer rounds of communication
         assert a["sent"] > 0
+
+
+@pytest.mark.parametrize("stencil,g,world,nr,steps", [("test_boundary_3d", (40, 36, 48), 2, (2, 1, 1), 4), ("test_boundary_3d", (40, 36, 48), 2, (1, 1, 2), 3),
+                                                     ("test_boundary_3d", (40, 36, 48), 8, None, 4), ("awp_abc", (48, 40, 56), 2, (1, 2, 1), 2)])
+def test_wave_front_tiling_across_ranks_with_sub_domain_parts(gpu, stencil, g, world, nr, steps, monkeypatch):
+    """with -Mbt 2 and neighbours the early phases of a group run on boxes grown into the neighbours'
+    domains; parts under a domain condition (IF_DOMAIN: test_boundary_3d's two half-space equations, awp_abc's sponge layers and
+    free surface) are launched over the bounding box of their condition, which therefore has to be found over the GROWN box (the
+    reference: find_bounding_boxes over ext_bb, setup.cpp:1000-1075) -- clipped to the rank box the parts were skipped out there
+    and the next phase read stale values near the rank boundary.  The assembled result equals the one-rank run bit for bit."""
+    monkeypatch.setenv("YASK_TEST_TRANSPORT", "ipc")
+    monkeypatch.setenv("YASK_TEST_EXTRA_OPTS", "-Mbt 2")
+    wf = _run_ranks(world, "run", stencil=stencil, g=g, nr=nr, steps=steps)
+    full = _assemble(wf, stencil, g)
+    one = _one_rank(stencil, g, steps)
+    for n in FIELDS[stencil]:
+        assert np.isfinite(one[n]).all()
+        assert np.array_equal(full[n], one[n]), (n, float(np.abs(full[n] - one[n]).max()), np.argwhere(full[n] != one[n])[:4].tolist())
+    groups = (steps + 1) // 2
+    for _, _, _, a in wf:
+        assert a["msgs"] == (groups + 1) * (7 if world == 8 else 1), a["msgs"]      # the wave-front schedule really ran

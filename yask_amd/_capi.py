@@ -35,7 +35,7 @@ class YkReduction(C.Structure):
 
 class YkHaloMsg(C.Structure):
     _fields_ = [("peer", C.c_int), ("send_buf", C.c_void_p), ("recv_buf", C.c_void_p),
-                ("send_bytes", C.c_size_t), ("recv_bytes", C.c_size_t), ("tag", C.c_int)]
+                ("send_bytes", C.c_size_t), ("recv_bytes", C.c_size_t), ("tag", C.c_int), ("key", C.c_int)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(YkHaloMsg), C.c_void_p)
@@ -75,6 +75,7 @@ PROTOTYPES = {
     "yk_rendezvous_bcast": (C.c_int, [C.c_int, C.c_int, _S, C.c_int, C.c_void_p, C.c_size_t]),
     "yk_tcp_mesh_check": (C.c_int, [C.c_int, C.c_int, _S, C.c_int, C.POINTER(C.c_longlong)]),
     "yk_env_transport_loopback": (C.c_int, [_H, C.c_size_t]),
+    "yk_env_get_transport_counters": (C.c_int, [_H, C.POINTER(C.c_longlong), C.c_int]),
     "yk_env_probe_bandwidth": (C.c_double, [_H, C.c_int, C.c_size_t, C.c_int]),
     "yk_solution_set_min_pad_size": (C.c_int, [_H, _S, idx_t]),
     "yk_solution_get_min_pad_size": (idx_t, [_H, _S]),
@@ -104,6 +105,7 @@ PROTOTYPES = {
     "yk_env_sum_over_ranks": (idx_t, [_H, idx_t]),
     "yk_env_set_trace_enabled": (None, [_H, C.c_int]),
     "yk_env_set_ranks": (C.c_int, [_H, C.c_int, C.c_int]),
+    "yk_env_get_device_bus_id": (C.c_int, [_H, C.c_char_p, C.c_int]),
     "yk_env_set_transport": (C.c_int, [_H, EXCHANGE_FN, EXCHANGE_FN, ALLREDUCE_FN, C.c_void_p]),
     "yk_rccl_get_unique_id": (C.c_int, [C.c_void_p]),
     "yk_env_init_rccl": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),

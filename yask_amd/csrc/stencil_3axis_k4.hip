@@ -5,6 +5,7 @@
 namespace ykh {
 using namespace ykh_gen_3axis;
 void s3axis_variants_k4(PartImpl& p) {
+#ifdef YKH_PROFILING      // sweep shapes: measured, documented, never selected -- built with `make YKH_PROFILING=1` only
     p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_TRIP, 1, 2, 4>());      // tile 128x32 (the large-grid shape)
     p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_TRIP2, 1, 2, 4>());
     // (planes two ahead on this shape: 256 VGPRs + 44 ... 92 B of scratch per lane with either rotation: not instantiated)
@@ -19,7 +20,10 @@ void s3axis_variants_k4(PartImpl& p) {
     p.variants.push_back(starlin_variant<part_1, 2, 64, 16, 1, ROT_TRIP2, 1, 4, 4>());
     p.variants.push_back(starlin_variant<part_1, 2, 32, 32, 1, ROT_TRIP2, 9, 4, 4>());    // tile 64 x 32 on 1024 threads
     p.variants.push_back(starlin_variant<part_1, 2, 64, 16, 1, ROT_TRIP2, 25, 4, 4>());   // + operands two planes ahead
+#endif
     p.variants.push_back(starlin_variant<part_1, 2, 32, 16, 2, ROT_UNROLL, 1 | 64, 2, 4>());   // the default shape + cheap tail planes (_tl)
+#ifdef YKH_PROFILING      // sweep shapes: measured, documented, never selected -- built with `make YKH_PROFILING=1` only
     p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_MOVE, 1 | 64, 2, 4>());      // the large-grid shape + cheap tail planes
+#endif
 }
 }  // namespace ykh

@@ -6,8 +6,10 @@
 namespace ykh {
 using namespace ykh_gen_iso3dfd;
 void iso3dfd_variants_k2(PartImpl& p) {
+#ifdef YKH_PROFILING      // sweep shapes: measured, documented, never selected -- built with `make YKH_PROFILING=1` only
     p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 1, 2, 4, 0>());
     p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 0, 2, 4, 0>());
+#endif
     p.variants.push_back(starlin_variant_planned<part_1, 4, 32, 16, 1, ROT_MOVE, 1, 2, 4>());      // (+ twin for planned launches: the multi-rank tests' shape)
     p.variants.push_back(starlin_variant<part_1, 4, 32, 8, 1, ROT_MOVE, 1, 3, 4, 0>());
 }

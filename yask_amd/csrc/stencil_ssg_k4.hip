@@ -4,6 +4,7 @@
 namespace ykh {
 using namespace ykh_gen_ssg;
 void ssg_variants_k4(PartImpl& p) {
+#ifdef YKH_PROFILING      // sweep shapes: measured, documented, never selected -- built with `make YKH_PROFILING=1` only
     p.variants.push_back(march_variant<part_2, 2, 64, 8, 2, 2, false, 1>());   // two rows per thread: tile 128x16
     p.variants.push_back(march_variant<part_2, 2, 64, 8, 2, 2, false, 2>());
     p.variants.push_back(march_variant<part_2, 4, 32, 16, 2, 1, false, 1>());  // 16-byte lanes, tile 128x16
@@ -16,7 +17,10 @@ void ssg_variants_k4(PartImpl& p) {
     p.variants.push_back(march_variant<part_2, 4, 16, 32, 2, 1, false, 1, 1>());   // tile 64x32: less y halo, more z halo
     p.variants.push_back(march_variant<part_2, 2, 64, 8, 2, 2, false, 1, 1>());    // 8-byte lanes, two rows per thread, nt
     p.variants.push_back(march_variant<part_2, 2, 32, 16, 2, 2, false, 1, 1>());   // tile 64x32 with 8-byte lanes
+#endif
     p.variants.push_back(march_variant<part_2, 4, 32, 16, 2, 1, false, 1, 3>());   // 128x16, nt + halo rings
+#ifdef YKH_PROFILING      // sweep shapes: measured, documented, never selected -- built with `make YKH_PROFILING=1` only
     p.variants.push_back(march_variant<part_2, 2, 64, 8, 2, 1, false, 1, 3>());    // 8-byte lanes, nt + halo rings
+#endif
 }
 }  // namespace ykh

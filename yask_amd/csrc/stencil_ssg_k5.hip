@@ -5,13 +5,17 @@
 namespace ykh {
 using namespace ykh_gen_ssg;
 void ssg_variants_k5(PartImpl& p) {
+#ifdef YKH_PROFILING      // sweep shapes: measured, documented, never selected -- built with `make YKH_PROFILING=1` only
     p.variants.push_back(march_variant<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4>());             // 144 v_sub_f32 -> 72 v_pk_fma_f32
     p.variants.push_back(march_variant<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 8>());             // 3 divisions per point: ~130 -> ~18 instructions
     p.variants.push_back(march_variant<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8>());
+#endif
     p.variants.push_back(march_variant_planned<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 16>());        // exact arithmetic, trips of 2
     p.variants.push_back(march_variant_planned<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8 | 16>());
+#ifdef YKH_PROFILING      // sweep shapes: measured, documented, never selected -- built with `make YKH_PROFILING=1` only
     p.variants.push_back(march_variant<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8 | 32>());    // trips of 4: 256 VGPRs, no spill
     p.variants.push_back(march_variant<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8 | 16 | 128>());   // + late refill of the centre-only operands
     p.variants.push_back(march_variant<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8 | 32 | 128>());
+#endif
 }
 }  // namespace ykh

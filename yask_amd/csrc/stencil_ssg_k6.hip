@@ -4,16 +4,22 @@
 namespace ykh {
 using namespace ykh_gen_ssg;
 void ssg_variants_k6(PartImpl& p) {
+#ifdef YKH_PROFILING      // sweep shapes: measured, documented, never selected -- built with `make YKH_PROFILING=1` only
     p.variants.push_back(march_variant<part_2, 4, 32, 16, 2, 1, false, 1, 3 | 4>());             // (spills 2 registers)
+#endif
     p.variants.push_back(march_variant_planned<part_2, 4, 32, 16, 2, 1, false, 1, 3 | 8>());             // 5 divisions per point: ~200 -> ~30 instructions
+#ifdef YKH_PROFILING      // sweep shapes: measured, documented, never selected -- built with `make YKH_PROFILING=1` only
     p.variants.push_back(march_variant<part_2, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8>());         // (spills 2 registers)
     p.variants.push_back(march_variant<part_2, 4, 32, 16, 2, 1, false, 1, 1 | 4 | 8>());         // without the halo rings: fits
     p.variants.push_back(march_variant<part_2, 4, 32, 16, 2, 1, false, 1, 3 | 8 | 16>());        // trips of 2 (spills 6)
     // late refill of the nine centre-only operands (_lo: each held once instead of twice, 256 -> 232 VGPRs): everything fits
+#endif
     p.variants.push_back(march_variant_planned<part_2, 4, 32, 16, 2, 1, false, 1, 3 | 8 | 128>());
+#ifdef YKH_PROFILING      // sweep shapes: measured, documented, never selected -- built with `make YKH_PROFILING=1` only
     p.variants.push_back(march_variant<part_2, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8 | 128>());
     p.variants.push_back(march_variant<part_2, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8 | 16 | 128>());
     p.variants.push_back(march_variant<part_2, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8 | 32 | 128>());
+#endif
     p.variants.push_back(march_variant_planned<part_2, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 16 | 128>());      // exact arithmetic
 }
 }  // namespace ykh

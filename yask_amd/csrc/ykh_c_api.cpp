@@ -105,6 +105,16 @@ yk_idx_t yk_env_sum_over_ranks(yk_env_h e, yk_idx_t v) {
     YK_CATCH(0)
 }
 void yk_env_set_trace_enabled(yk_env_h e, int en) { if (e) e->env->trace = en != 0; }
+int yk_env_get_device_bus_id(yk_env_h e, char* out, int cap) {
+    YK_TRY
+    if (!e || !out || cap < 2) YKH_THROW("get_device_bus_id: bad arguments");
+    int dev = 0;
+    YKH_HIP(hipGetDevice(&dev));
+    YKH_HIP(hipDeviceGetPCIBusId(out, cap, dev));
+    out[cap - 1] = 0;
+    return (int)std::strlen(out);
+    YK_CATCH(-1)
+}
 int yk_env_set_ranks(yk_env_h e, int rank, int n) {
     YK_TRY
     if (!e) YKH_THROW("null env handle");
@@ -112,14 +122,24 @@ int yk_env_set_ranks(yk_env_h e, int rank, int n) {
     return 0;
     YK_CATCH(1)
 }
+// control-plane counters of the installed halo transport (ykh_ipc.cpp): out[0] registrations sent over the TCP mesh, out[1]
+// their bytes, out[2] collective begin calls (one per run_solution() / exchange_halos()), out[3] collective resets, out[4]
+// device operations enqueued (flag kernels + copies), out[5] kind of mailbox memory; returns how many it knows, 0 = none
+int yk_env_get_transport_counters(yk_env_h e, long long* out, int cap) {
+    YK_TRY
+    if (!e) YKH_THROW("null env handle");
+    if (!e->env->exch_counters || !out || cap <= 0) return 0;
+    return e->env->exch_counters(e->env->user, out, cap);
+    YK_CATCH(-1)
+}
 int yk_env_set_transport(yk_env_h e, yk_exchange_fn start, yk_exchange_fn wait, yk_allreduce_fn ar, void* user) {
     YK_TRY
     if (!e) YKH_THROW("null env handle");
     static_assert(sizeof(yk_halo_msg) == sizeof(HaloMsg), "yk_halo_msg must mirror ykh::HaloMsg");
+    e->env->drop_transport();               // a built-in transport installed earlier goes, with every hook it had set
     e->env->exch_start = reinterpret_cast<ykh_exchange_fn>(start);
     e->env->exch_wait = reinterpret_cast<ykh_exchange_fn>(wait);
     e->env->allreduce = ar;
-    if (e->env->user && e->env->user_free) e->env->user_free(e->env->user);     // a built-in transport installed earlier
     e->env->user = user;
     e->env->user_free = nullptr;            // the host owns its own state
     return 0;
@@ -291,7 +311,7 @@ int yk_env_transport_loopback(yk_env_h e, size_t nbytes) {
     YKH_HIP(hipMemcpyAsync(b.s, h.data(), nbytes, hipMemcpyHostToDevice, b.st));
     YKH_HIP(hipMemsetAsync(b.r, 0, nbytes, b.st));
     HaloMsg m;
-    m.peer = env.rank; m.send_buf = b.s; m.recv_buf = b.r; m.send_bytes = m.recv_bytes = nbytes; m.tag = 13;
+    m.peer = env.rank; m.send_buf = b.s; m.recv_buf = b.r; m.send_bytes = m.recv_bytes = nbytes; m.tag = 13; m.key = 0;
     if (env.exch_start(env.user, 1, &m, (void*)b.st) != 0) YKH_THROW("transport loop-back: start failed");
     if (env.exch_wait && env.exch_wait(env.user, 1, &m, (void*)b.st) != 0) YKH_THROW("transport loop-back: wait failed");
     YKH_HIP(hipMemcpyAsync(back.data(), b.r, nbytes, hipMemcpyDeviceToHost, b.st));
@@ -761,6 +781,7 @@ int yk_var_fuse_vars(yk_var_h v, yk_var_h src) {
     for (size_t i = 0; i < a->dims.size(); i++)
         if (a->dims[i].name != b->dims[i].name) YKH_THROW("fuse_vars: dims of '" + a->name + "' and '" + b->name + "' differ");
     // (a var used by its solution's kernels must keep the geometry the kernels were given: layouts must agree)
+    if (a->nslots != b->nslots) YKH_THROW("fuse_vars: storage layouts of '" + a->name + "' and '" + b->name + "' differ (step allocations)");
     if ((b->is_allocated() || a->soln->prepared || b->soln->prepared) && !yk_var_is_storage_layout_identical(v, src))
         YKH_THROW("fuse_vars: storage layouts of '" + a->name + "' and '" + b->name + "' differ");
     b->before_device_use();

@@ -161,6 +161,7 @@ void Solution::exchange_build_and_pack(hipStream_t st) {
                     m.send_buf = plane_ptr(ss.lo[0]); m.send_bytes = (size_t)(ss.n[0] * v.stride[0]) * elem_bytes();
                     m.recv_buf = plane_ptr(rs.lo[0]); m.recv_bytes = (size_t)(rs.n[0] * v.stride[0]) * elem_bytes();
                     m.tag = (x->nb.ofs[0] + 1) * 9 + 4;
+                    m.key = ordinal * 4096 + (ss.var * 16 + slot) + 1;
                     msgs.push_back(m);
                     x->send_now += m.send_bytes; x->recv_now += m.recv_bytes;
                 }
@@ -183,6 +184,7 @@ void Solution::exchange_build_and_pack(hipStream_t st) {
         m.send_bytes = x->send_now; m.recv_bytes = x->recv_now;
         // tag encodes the direction so that both messages between a pair of ranks are distinct
         m.tag = (x->nb.ofs[0] + 1) * 9 + (x->nb.ofs[1] + 1) * 3 + (x->nb.ofs[2] + 1);
+        m.key = ordinal * 4096;
         msgs.push_back(m);
     }
     launch_halo_move(segs, /*pack=*/true, elem_bytes(), st);
@@ -281,6 +283,8 @@ void Solution::exchange_halos_all() {
     // reference's set_all_neighbor_vars_dirty() (context.cpp:234, halo.cpp:84-161 keeps self/others flags).
     for (auto& v : vars) v->before_device_use();      // raw buffers handed out: the caller may have written through them
     exch_half_ = -1;                                   // whole faces
+    if (env->nranks > 1 && !xfers.empty() && env->exch_begin && env->exch_begin(env->user) != 0)
+        YKH_THROW("halo-exchange transport failed to agree on its state across the ranks");
     if (env->nranks > 1)
         for (auto& v : vars) v->set_dirty_all(true);
     exchange_halos(0, 0, true, false);

@@ -336,10 +336,10 @@ int yk_env_init_tcp(yk_env_h e, int rank, int nranks, const char* addr, int base
         e->env->set_ranks(rank, nranks);
         TcpState* st = tcp_connect_mesh(rank, nranks, addr && *addr ? addr : "127.0.0.1", base_port);
         if (!st) { fprintf(stderr, "yask tcp transport: rank %d could not connect the mesh\n", rank); return 1; }
+        e->env->drop_transport();
         e->env->exch_start = tcp_start;
         e->env->exch_wait = tcp_wait;
         e->env->allreduce = tcp_allreduce;
-        if (e->env->user && e->env->user_free) e->env->user_free(e->env->user);
         e->env->user = st;
         e->env->user_free = [](void* p) {
             TcpState* s = static_cast<TcpState*>(p);
@@ -378,6 +378,7 @@ int yk_env_init_mirror(yk_env_h e, int rank, int nranks) {
         e->env->set_ranks(rank, nranks);
         MirrorState* ms = new MirrorState;
         if (const char* g = getenv("YASK_MIRROR_LINK_GBPS")) ms->gbps = atof(g);
+        e->env->drop_transport();
         e->env->exch_start = [](void* u, int n, const ykh::HaloMsg* m, void* stream) -> int {
             MirrorState* st = static_cast<MirrorState*>(u);
             size_t most = 0;
@@ -397,9 +398,6 @@ int yk_env_init_mirror(yk_env_h e, int rank, int nranks) {
         };
         e->env->exch_wait = [](void*, int, const ykh::HaloMsg*, void*) -> int { return 0; };
         e->env->allreduce = [](void*, int, long long*) -> int { return 0; };       // every rank would report what this one does
-        e->env->exch_reset = nullptr;
-        e->env->exch_check = nullptr;
-        if (e->env->user && e->env->user_free) e->env->user_free(e->env->user);
         e->env->user = ms;
         // (the 8-byte word is not given back: a synchronous hipMalloc / hipMemset / hipFree sequence per env left every LATER solution of
         //  the process with slow cross-stream hand-offs -- small kernels 4x slower, 0.05-0.15 ms between dependent launches, measured

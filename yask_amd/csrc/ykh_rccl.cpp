@@ -114,10 +114,10 @@ int yk_env_init_rccl(yk_env_h e, const void* id128, int rank, int nranks) {
         if (hipMalloc(&st->dscalar, sizeof(long long)) != hipSuccess) return 1;
         int rc = rccl().CommInitRank(&st->comm, nranks, id, rank);
         if (rc != 0) { fprintf(stderr, "ncclCommInitRank failed: %s\n", rccl().GetErrorString(rc)); return 1; }
+        e->env->drop_transport();               // an earlier built-in transport
         e->env->exch_start = rccl_start;
         e->env->exch_wait = rccl_wait;
         e->env->allreduce = rccl_allreduce;
-        if (e->env->user && e->env->user_free) e->env->user_free(e->env->user);     // an earlier built-in transport
         e->env->user = st;
         e->env->user_free = [](void* p) {
             RcclState* s = static_cast<RcclState*>(p);

@@ -124,6 +124,12 @@ struct HaloMsg {
     size_t send_bytes;
     size_t recv_bytes;
     int tag;
+    // Which of the receiver's buffers this message lands in, named the SAME way on both ends of the link: 0 = the neighbour's
+    // packed receive buffer for this direction, (var ordinal * 16 + step slot) + 1 = the planes of that var slot (in-place x
+    // faces), plus the solution's ordinal within its env x 4096 (solutions are created in the same order on every rank; two
+    // solutions of one env have different buffers).  A transport that maps the peer's buffers (ykh_ipc.cpp) learns the address of
+    // a (peer, tag, key) once.
+    int key;
 };
 typedef int (*ykh_exchange_fn)(void* user, int nmsgs, const HaloMsg* msgs, void* stream);
 typedef int (*ykh_allreduce_fn)(void* user, int op /*0 sum,1 min,2 max*/, long long* val);
@@ -137,10 +143,20 @@ public:
     ykh_exchange_fn exch_wait = nullptr;    // make `stream` wait until they have landed
     ykh_allreduce_fn allreduce = nullptr;
     void (*exch_reset)(void* user) = nullptr;   // optional: buffers a transport may have cached addresses of are being freed / re-allocated
+    int (*exch_begin)(void* user) = nullptr;    // optional, COLLECTIVE: called by every rank before the first exchange of a run_solution() / exchange_halos() call
     int (*exch_check)(void* user) = nullptr;    // optional: non-zero if an exchange failed asynchronously (called when the streams have drained)
+    int (*exch_counters)(void* user, long long* out, int cap) = nullptr;   // optional: control-plane counters (yk_env_get_transport_counters)
     void* user = nullptr;
     void (*user_free)(void*) = nullptr;     // releases `user` (built-in transports own their state; host callbacks do not)
     bool trace = false;
+    int solutions_made = 0;                 // ordinal of the next Solution of this env (HaloMsg::key)
+    // a new transport is about to be installed: the old one's state goes, and so does every hook it had set
+    void drop_transport() {
+        if (user && user_free) user_free(user);
+        user = nullptr; user_free = nullptr;
+        exch_start = exch_wait = nullptr; allreduce = nullptr;
+        exch_reset = nullptr; exch_begin = nullptr; exch_check = nullptr; exch_counters = nullptr;
+    }
     Env();
     ~Env() { if (user && user_free) user_free(user); }
     Env(const Env&) = delete;
@@ -309,6 +325,7 @@ public:
     ~Solution();
 
     std::shared_ptr<Env> env;
+    int ordinal = 0;                        // n-th solution made in this env (the same on every rank): part of HaloMsg::key
     const SolnImpl& impl;
     const SolnMeta* meta;
     int ndd;                                   // number of domain dims
@@ -429,6 +446,7 @@ public:
     struct StepGraph { std::string key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; idx_t steps = 0; idx_t nodes = 0; };
     std::vector<StepGraph> step_graph_cache;           // most recently used last; dropped by prepare() / end() / the tuner
     void drop_step_graphs();
+    void note_storage_changed();                       // a var's allocation was made, freed or shared: transports forget cached addresses
     idx_t slot_period() const;                         // steps after which every var is back in the same slots (lcm of the slot counts)
     bool step_graph_eligible() const;                  // every launch of a step depends on t through the base pointers only
     bool step_graph_wanted() const;

@@ -22,31 +22,11 @@
 #include <sstream>
 
 #include "ykh_runtime.hpp"
+#include "ykh_solution_internal.hpp"
 
 namespace ykh {
 
 std::string version_string() { return "4.05.04-cdna4_hip"; }
-
-static inline idx_t ceil_div(idx_t a, idx_t b) { return (a + b - 1) / b; }
-
-// Sets a member flag for a scope and puts the old value back on every way out (a throwing launch must not leave
-// `in_outer_loop`, `launching_exterior`, ... set for the calls that follow).
-template <typename T>
-struct ScopedSet {
-    T& ref; T old;
-    ScopedSet(T& r, T v) : ref(r), old(r) { ref = v; }
-    ~ScopedSet() { ref = old; }
-    ScopedSet(const ScopedSet&) = delete;
-    ScopedSet& operator=(const ScopedSet&) = delete;
-};
-
-// grid of the point kernels / cond_bb_kernel over a box (see point_of_thread(), ykh_device.hpp)
-static dim3 point_grid(const Box& b, int lane_dim) {
-    const idx_t n[3] = {b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]};
-    if (lane_dim == 2) return dim3((unsigned)ceil_div(n[2], 64), (unsigned)ceil_div(n[1], 4), (unsigned)n[0]);
-    if (lane_dim == 1) return dim3((unsigned)ceil_div(n[1], 64), (unsigned)ceil_div(n[0], 4), (unsigned)n[2]);
-    return dim3((unsigned)ceil_div(n[0], 64), (unsigned)ceil_div(n[1], 4), (unsigned)n[2]);
-}
 
 bool Box::empty() const {
     for (int d = 0; d < MAX_DOMAIN_DIMS; d++)
@@ -89,6 +69,7 @@ size_t variant_scratch_bytes(const KernelVariant& kv) {
 
 // ------------------------------------------------------------------ Solution basics
 Solution::Solution(std::shared_ptr<Env> e, const SolnImpl& im) : env(e), impl(im), meta(im.meta) {
+    ordinal = env->solutions_made++;
     ndd = 0;
     for (int i = 0; i < meta->ndims; i++) {
         const DimMeta& d = meta->dims[i];
@@ -461,103 +442,6 @@ void Solution::setup_rank() {
     }
 }
 
-// ------------------------------------------------------------------ var placement
-// A stencil kernel streams several arrays at the same logical position at the same time; where those arrays lie in physical
-// memory -- relative to each other and absolutely -- decides how often the streams meet in a DRAM channel or bank.  Measured
-// (tools/placement_probe.py, profiles/r03h_placement): the same kernel in the same process runs 3-4 % apart on two sets of
-// freshly allocated arrays (iso3dfd 1024^3: 2.88 ... 3.03 ms per step, ssg 512^3: 2.78 ... 2.98), each set stable to 0.1 %.
-// 256-byte skews of the bases do not control it, and neither does one shared allocation with chosen spacings (the reference's
-// -bundle_allocs, alloc.cpp:343-452: measured here, ssg then runs uniformly at the slow end) -- the address hash takes high
-// bits.  What works is what the numbers say: draw several placements, time a step on each, keep the fastest.  That is done
-// once, in prepare_solution(), while the arrays are still empty: every further set is allocated WHILE the best one so far is
-// held (so the allocator must hand out other memory), a few steps are timed on it, and the loser is freed.
-void Solution::tune_placement() {
-    placement_ms.clear();
-    placement_chosen = 0;
-    if (impl.parts.empty()) return;
-    for (size_t p = 0; p < impl.parts.size(); p++) if (part_variant[p] < 0) return;
-    std::vector<Var*> mv;
-    size_t total = 0;
-    for (auto& v : vars) if (!v->fixed_size && v->is_allocated() && !v->fuse_group) { mv.push_back(v.get()); total += v->bytes(); }
-    for (auto& v : scratch_vars) if (v->is_allocated()) { mv.push_back(v.get()); total += v->bytes(); }
-    if (mv.empty()) return;
-    struct Ev {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        ~Ev() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
-    } ev;
-    YKH_HIP(hipEventCreate(&ev.e0));
-    YKH_HIP(hipEventCreate(&ev.e1));
-    const Box rb = rank_box();
-    auto time_steps = [&]() -> float {
-        // O(1) hashed values, no zeros (timed on zeroed arrays the ranking did not hold: all-zero data runs ~3 % faster)
-        for (size_t k = 0; k < mv.size(); k++) mv[k]->set_elements_hash(1.0, 0.1, (int)k);
-        float ms_min = 0.f;
-        for (int r = 0; r <= 3; r++) {                 // r = 0: untimed (first touch of the new addresses)
-            YKH_HIP(hipEventRecord(ev.e0, compute_stream));
-            for (int st = 0; st < meta->n_stages; st++)
-                for (int k = 0; k < meta->stages[st].n_parts; k++) launch_part(meta->stages[st].parts[k], r, rb, compute_stream);
-            YKH_HIP(hipEventRecord(ev.e1, compute_stream));
-            YKH_HIP(hipEventSynchronize(ev.e1));
-            float ms = 0.f;
-            YKH_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
-            if (r > 0 && (ms_min == 0.f || ms < ms_min)) ms_min = ms;
-        }
-        return ms_min;
-    };
-    // a set of allocations = (owner, alloc_ptr, dptr) per var; the vars always point at the set being timed; a set nobody
-    // points at any more is freed when its owners go (Var::own_allocation)
-    struct PlacedVar { std::shared_ptr<void> own; void* alloc; void* data; };
-    typedef std::vector<PlacedVar> PtrSet;
-    auto current = [&]() { PtrSet s; for (auto* v : mv) s.push_back({v->alloc_owner, v->alloc_ptr, v->dptr}); return s; };
-    auto attach = [&](const PtrSet& s) { for (size_t k = 0; k < mv.size(); k++) mv[k]->adopt_storage(s[k].own, s[k].alloc, s[k].data, mv[k]->alloc_bytes); };
-    auto free_set = [&](PtrSet& s) { s.clear(); };
-    PtrSet best = current();
-    // A GPU that idled is still raising its clocks: step until the step time has settled (three groups of steps within 0.5 %,
-    // 1 s at most) -- otherwise the sets timed later simply look faster (seen on a cold box: the "best" set then ran 4 % slower
-    // than it had measured).  And every candidate is compared with the incumbent timed right before it, not with a number from
-    // earlier.
-    {
-        float g[3] = {0.f, 0.f, 0.f};
-        const auto w0 = std::chrono::steady_clock::now();
-        for (int it = 0; it < 200; it++) {
-            g[it % 3] = time_steps();
-            const float lo = std::min({g[0], g[1], g[2]}), hi = std::max({g[0], g[1], g[2]});
-            if (it >= 2 && lo > 0.f && hi - lo <= std::max(lo * 0.005f, 0.004f)) break;      // (short steps: 4 us of timer noise)
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() > 1.0) break;
-        }
-    }
-    float best_ms = time_steps();
-    placement_ms.push_back(best_ms);
-    for (idx_t trial = 1; trial < placement_trials; trial++) {
-        size_t free_b = 0, tot_b = 0;
-        if (hipMemGetInfo(&free_b, &tot_b) != hipSuccess) { (void)hipGetLastError(); break; }
-        if ((double)free_b < 1.25 * (double)total + (double)((size_t)1 << 30)) break;      // no room for another set
-        PtrSet cand;
-        bool ok = true;
-        for (auto* v : mv) {
-            const size_t skew = (size_t)((char*)v->dptr - (char*)v->alloc_ptr), nb = std::max<size_t>(v->bytes(), 256);
-            void* p = nullptr;
-            if (hipMalloc(&p, nb + skew) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
-            cand.push_back({Var::own_allocation(p), p, (char*)p + skew});
-            if (hipMemsetAsync((char*)p + skew, 0, nb, compute_stream) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
-        }
-        if (!ok) { free_set(cand); break; }
-        float ms = 0.f, inc = 0.f;
-        try {
-            inc = time_steps();                  // the incumbent, now
-            attach(cand);
-            ms = time_steps();
-        } catch (...) { attach(best); free_set(cand); throw; }
-        placement_ms.push_back(ms);
-        if (ms < inc) { free_set(best); best = cand; best_ms = ms; placement_chosen = (int)placement_ms.size() - 1; }
-        else { attach(best); free_set(cand); best_ms = inc; }
-    }
-    attach(best);
-    // the trial data and results go: back to the zeros a fresh allocation holds
-    for (auto* v : mv) YKH_HIP(hipMemsetAsync(v->dptr, 0, std::max<size_t>(v->bytes(), 256), compute_stream));
-    YKH_HIP(hipStreamSynchronize(compute_stream));
-}
-
 // ------------------------------------------------------------------ prepare / end
 void Solution::prepare() {
     for (auto& h : before_prepare) h(*this);
@@ -638,7 +522,19 @@ void Solution::prepare() {
             if (!dbb) YKH_HIP(hipMalloc(&dbb, 8 * sizeof(int)));
             const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
             YKH_HIP(hipMemcpyAsync(dbb, init, sizeof(init), hipMemcpyHostToDevice, compute_stream));
-            const Box rb = rank_box();
+            // Wave-front tiling across ranks evaluates the early phases of a group on boxes grown INTO the neighbours' domains
+            // (run_wavefront_multi): the condition's box must cover those points too (the reference finds its bounding boxes over
+            // the extended box, ext_bb, setup.cpp:1000-1075) -- clipped to the rank box, a sub-domain part would never be
+            // evaluated there and the next phase would read stale values near the rank boundary.
+            Box rb = rank_box();
+            if (wf_multi()) {
+                bool lo[MAX_DOMAIN_DIMS], hi[MAX_DOMAIN_DIMS];
+                neighbor_sides(lo, hi);
+                for (int d = 0; d < ndd; d++) {
+                    if (lo[d]) rb.lo[d] -= wf_ext_[d];
+                    if (hi[d]) rb.hi[d] += wf_ext_[d];
+                }
+            }
             PartArgs a;
             fill_part_args((int)p, 0, rb, a);
             pi.cond_bb(a, point_grid(rb, a.lane_dim), dbb, compute_stream);
@@ -967,619 +863,6 @@ void Solution::launch_part(int part, idx_t t, const Box& box_in, hipStream_t s) 
     launch_part_variant(part, part_variant[part], part_xchunk[part], t, b, s);
 }
 
-// ------------------------------------------------------------------ exterior / interior split of a decomposed run
-// Interior box of a rank with neighbours on the given sides (alloc.cpp:686-723 `mpi_interior`): the exterior is what the
-// neighbours need, computed first.  Width per dim = the halo (or -min_exterior); in z one marching tile (see prepare()).
-Box Solution::interior_for(const bool* has_lo, const bool* has_hi) const {
-    Box ib = rank_box();
-    for (int d = 0; d < ndd; d++) {
-        idx_t w = std::max<idx_t>(std::max(shared_pad_l_[d], shared_pad_r_[d]), min_exterior);
-        if (d == 2 && ndd == 3 && min_exterior == 0 && !impl.parts.empty() && part_variant[0] >= 0) {
-            const KernelVariant& kv = impl.parts[0].variants[part_variant[0]];
-            const idx_t tz = kv.star && kv.rx == 0 ? kv.tz : 0;
-            if (tz > w && local_size[2] >= ((has_lo[d] ? 1 : 0) + (has_hi[d] ? 1 : 0) + 1) * tz) w = tz;
-        }
-        if (has_lo[d]) ib.lo[d] += w;
-        if (has_hi[d]) ib.hi[d] -= w;
-    }
-    return ib;
-}
-// exterior slabs first (context.cpp:377-444) ...
-void Solution::launch_exterior(const StageMeta& sm, idx_t t, const Box& ib) {
-    ScopedSet<bool> ext(launching_exterior, true);
-    Box rem = rank_box();
-    for (int d = 0; d < ndd; d++) {
-        if (ib.lo[d] > rem.lo[d]) {
-            Box s = rem; s.hi[d] = ib.lo[d];
-            for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, s, compute_stream);
-            rem.lo[d] = ib.lo[d];
-        }
-        if (ib.hi[d] < rem.hi[d]) {
-            Box s = rem; s.lo[d] = ib.hi[d];
-            for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, s, compute_stream);
-            rem.hi[d] = ib.hi[d];
-        }
-    }
-}
-// ... then the interior, while the halos travel.  The marching kernels keep one workgroup per CU resident for a whole
-// launch, so a single interior launch would leave no CU for the comm stream until it ends: the interior is split along x
-// into a few back-to-back launches; at each boundary CUs drain and the (higher priority) pack / send-recv / unpack
-// kernels get in.
-// The slabs of one stage are independent boxes (disjoint writes, reads of the previous stage's data only): each goes to its
-// own high-priority stream, ordered after everything queued on the compute stream so far (-hip_ext_streams 1 / 2).  Not the
-// default: on one GPU the cross-stream dependencies cost more than the idle CUs of thin slabs (ykh_runtime.hpp).
-int Solution::launch_exterior_concurrent(const StageMeta& sm, idx_t t, const Box& ib) {
-    if (!ev_stage) YKH_HIP(hipEventCreateWithFlags(&ev_stage, hipEventDisableTiming));
-    YKH_HIP(hipEventRecord(ev_stage, compute_stream));
-    int n = 0;
-    auto slab = [&](const Box& sb) {
-        if ((int)ext_streams.size() <= n) {
-            int lo = 0, hi = 0;
-            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
-            hipStream_t st = nullptr;
-            if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) != hipSuccess) YKH_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            ext_streams.push_back(st);
-            hipEvent_t e = nullptr;
-            YKH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ext_events.push_back(e);
-        }
-        YKH_HIP(hipStreamWaitEvent(ext_streams[n], ev_stage, 0));
-        for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, sb, ext_streams[n]);
-        YKH_HIP(hipEventRecord(ext_events[n], ext_streams[n]));
-        n++;
-    };
-    ScopedSet<bool> ext(launching_exterior, true);
-    Box rem = rank_box();
-    for (int d = 0; d < ndd; d++) {
-        if (ib.lo[d] > rem.lo[d]) { Box s = rem; s.hi[d] = ib.lo[d]; slab(s); rem.lo[d] = ib.lo[d]; }
-        if (ib.hi[d] < rem.hi[d]) { Box s = rem; s.lo[d] = ib.hi[d]; slab(s); rem.hi[d] = ib.hi[d]; }
-    }
-    return n;
-}
-// (parts that fill scratch vars share those arrays between the slabs: such stages keep the serial order)
-int Solution::exterior_mode(const StageMeta& sm) const {
-    for (int k = 0; k < sm.n_parts; k++)
-        if (impl.parts[sm.parts[k]].meta->is_scratch) return 0;
-    return has_outer ? 0 : (int)ext_streams_mode;
-}
-
-void Solution::launch_interior(const StageMeta& sm, idx_t t, const Box& ib) {
-    const idx_t nxi = ib.hi[0] - ib.lo[0];
-    const idx_t nsplit = std::max<idx_t>(1, std::min<idx_t>(overlap_splits, nxi / 64));
-    ScopedSet<bool> inter(launching_interior, true);
-    for (idx_t c = 0; c < nsplit; c++) {
-        Box b = ib;
-        b.lo[0] = ib.lo[0] + nxi * c / nsplit;
-        b.hi[0] = ib.lo[0] + nxi * (c + 1) / nsplit;
-        for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, b, compute_stream);
-    }
-}
-// What the compute side of one step costs a rank with neighbours on the given sides -- the same launches run() issues,
-// without any communication -- against the undivided box.  tools/decomp_cost.py; ms[0] = exterior, ms[1] = interior,
-// ms[2] = whole box in one piece.
-void Solution::time_decomposed_step(const bool* has_lo, const bool* has_hi, int reps, float* ms) {
-    if (!prepared) YKH_THROW("time_decomposed_step() called without calling prepare_solution() first");
-    const Box ib = interior_for(has_lo, has_hi), rb = rank_box();
-    if (ib.empty()) YKH_THROW("time_decomposed_step(): no interior left");
-    hipEvent_t e[4];
-    for (auto& x : e) YKH_HIP(hipEventCreate(&x));
-    float acc[3] = {0, 0, 0};
-    const idx_t wf_steps = std::max<idx_t>(mega_block_size[0], block_size[0]);
-    if (wf_steps > 1 && wf_multi()) {
-        // wave-front tiling across ranks: ms[1] = one step's share of a group's launches (extended, shrinking boxes; no exchange),
-        // ms[2] = one plain sweep of the rank box, ms[0] = 0
-        for (int r = -1; r < reps; r++) {
-            YKH_HIP(hipEventRecord(e[0], compute_stream));
-            run_wavefront_multi((idx_t)(r + 1) * wf_steps, wf_steps, 1, has_lo, has_hi, /*exchange=*/false);
-            YKH_HIP(hipEventRecord(e[2], compute_stream));
-            for (idx_t k = 0; k < wf_steps; k++)
-                for (int st = 0; st < meta->n_stages; st++)
-                    for (int q = 0; q < meta->stages[st].n_parts; q++) launch_part(meta->stages[st].parts[q], r + 1, rb, compute_stream);
-            YKH_HIP(hipEventRecord(e[3], compute_stream));
-            YKH_HIP(hipEventSynchronize(e[3]));
-            if (r < 0) continue;
-            float m = 0;
-            YKH_HIP(hipEventElapsedTime(&m, e[0], e[2])); acc[1] += m / (float)wf_steps;
-            YKH_HIP(hipEventElapsedTime(&m, e[2], e[3])); acc[2] += m / (float)wf_steps;
-        }
-        for (int i = 0; i < 3; i++) ms[i] = acc[i] / (reps > 0 ? reps : 1);
-        for (auto& x : e) (void)hipEventDestroy(x);
-        return;
-    }
-    bool all_planned = true;
-    for (int st = 0; st < meta->n_stages; st++) all_planned &= planned_part(meta->stages[st]) >= 0;
-    // -hip_halves: the two half-launches of the pipelined schedule (ms[0] = the outer half, ms[1] = the inner one)
-    idx_t hq1 = 0, hq2 = 0;
-    const int plan_mode_used = (halves && halves_geometry(&hq1, &hq2)) ? 4 : -1;
-    for (int r = -1; r < reps; r++) {          // r = -1: warm-up
-        // (stage by stage as run() issues them; ms[0] = the exterior of the LAST stage, ms[0] + ms[1] = the whole step --
-        //  with -hip_ext_streams 2 the slabs run beside the interior and their time is part of ms[1])
-        YKH_HIP(hipEventRecord(e[0], compute_stream));
-        if (all_planned) {
-            // planned launches: ms[0] = from the start of the last stage's launch until its shell blocks have published their
-            // epoch (a waiter on the comm stream, as in run()), ms[1] = from there to the end of the launch
-            for (int st = 0; st < meta->n_stages; st++) {
-                const StageMeta& sm = meta->stages[st];
-                LaunchPlan* lp = get_launch_plan(planned_part(sm), has_lo, has_hi, false, plan_mode_used);
-                launch_planned(planned_part(sm), r + 1, *lp, true, compute_stream);
-                if (shell_event_pending) {
-                    shell_event_pending = false;
-                    YKH_HIP(hipStreamWaitEvent(comm_stream, ev_shell, 0));
-                } else {
-                    sig_pending = false;
-                    const unsigned* wp = sig_dev + 1;
-                    const unsigned wv = sig_epoch;
-                    launch_wait_words(1, &wp, &wv, sig_dev + 2, 20.0, comm_stream);
-                }
-                if (st == meta->n_stages - 1) YKH_HIP(hipEventRecord(e[1], comm_stream));
-            }
-            YKH_HIP(hipEventRecord(e[2], compute_stream));
-            for (int st = 0; st < meta->n_stages; st++)
-                for (int k = 0; k < meta->stages[st].n_parts; k++) launch_part(meta->stages[st].parts[k], r + 1, rb, compute_stream);
-            YKH_HIP(hipEventRecord(e[3], compute_stream));
-            YKH_HIP(hipEventSynchronize(e[3]));
-            YKH_HIP(hipStreamSynchronize(comm_stream));
-            if (r < 0) continue;
-            for (int i = 0; i < 3; i++) { float m = 0; YKH_HIP(hipEventElapsedTime(&m, e[i], e[i + 1])); acc[i] += m; }
-            continue;
-        }
-        for (int st = 0; st < meta->n_stages; st++) {
-            const StageMeta& sm = meta->stages[st];
-            const int mode = exterior_mode(sm);
-            int n_ext = 0;
-            if (mode == 0) launch_exterior(sm, r + 1, ib);
-            else {
-                n_ext = launch_exterior_concurrent(sm, r + 1, ib);
-                if (mode == 1) for (int i = 0; i < n_ext; i++) YKH_HIP(hipStreamWaitEvent(compute_stream, ext_events[i], 0));
-            }
-            if (st == meta->n_stages - 1) YKH_HIP(hipEventRecord(e[1], compute_stream));
-            launch_interior(sm, r + 1, ib);
-            if (mode == 2) for (int i = 0; i < n_ext; i++) YKH_HIP(hipStreamWaitEvent(compute_stream, ext_events[i], 0));
-        }
-        YKH_HIP(hipEventRecord(e[2], compute_stream));
-        for (int st = 0; st < meta->n_stages; st++)
-            for (int k = 0; k < meta->stages[st].n_parts; k++) launch_part(meta->stages[st].parts[k], r + 1, rb, compute_stream);
-        YKH_HIP(hipEventRecord(e[3], compute_stream));
-        YKH_HIP(hipEventSynchronize(e[3]));
-        if (r < 0) continue;
-        for (int i = 0; i < 3; i++) { float m = 0; YKH_HIP(hipEventElapsedTime(&m, e[i], e[i + 1])); acc[i] += m; }
-    }
-    for (int i = 0; i < 3; i++) ms[i] = acc[i] / (reps > 0 ? reps : 1);
-    for (auto& x : e) (void)hipEventDestroy(x);
-}
-
-// ------------------------------------------------------------------ planned launches (ykh_plan.cpp plan_blocks)
-void Solution::neighbor_sides(bool* has_lo, bool* has_hi) const {
-    for (int d = 0; d < MAX_DOMAIN_DIMS; d++) {
-        has_lo[d] = d < ndd && env->nranks > 1 && rank_index[d] > 0;
-        has_hi[d] = d < ndd && env->nranks > 1 && rank_index[d] < num_ranks[d] - 1;
-    }
-}
-void Solution::drop_launch_plans() {
-    for (auto& lp : launch_plans) if (lp && lp->dev) (void)hipFree(lp->dev);
-    launch_plans.clear();
-    planned_cache_.clear();
-}
-// A stage runs as a planned launch when it is ONE part on a marching kernel that reads block descriptors, over a plain
-// 3-D box: no scratch children (they would have to be evaluated per block), no sub-domain box, no per-point predicate.
-int Solution::planned_part(const StageMeta& sm) const {
-    if (!planned_launch || ndd != 3 || has_outer || force_scalar || sm.n_parts != 1) return -1;
-    const int part = sm.parts[0];
-    const PartMeta& pm = *impl.parts[part].meta;
-    if (pm.is_scratch || pm.has_step_cond || pm.has_step_cond_dev || part_needs_predicate(part)) return -1;
-    if ((size_t)part < part_has_bb.size() && part_has_bb[part]) return -1;
-    return planned_variant_of(part) >= 0 ? part : -1;
-}
-int Solution::planned_variant_of(int part) const {
-    if (planned_cache_.size() != impl.parts.size()) planned_cache_.assign(impl.parts.size(), -2);
-    if (planned_cache_[part] != -2) return planned_cache_[part];
-    auto remember = [&](int r) { planned_cache_[part] = r; return r; };
-    const PartImpl& pi = impl.parts[part];
-    int v = part_variant[part];
-    if (v < 0) return -1;
-    // the part runs on its static default: the shape named for planned launches (same arithmetic, room for the twin's registers)
-    if (variant_override.empty()) {
-        if (v == pi.default_variant && pi.planned_variant >= 0) v = pi.planned_variant;
-        else if (v == pi.exact_div_variant && pi.planned_exact_variant >= 0) v = pi.planned_exact_variant;
-    }
-    const KernelVariant& kv = pi.variants[v];
-    if (!kv.launch_desc || !kv.star || kv.rx != 0) return remember(-1);
-    if (kv.func_desc) {          // a twin that spilled registers is never worth it
-        hipFuncAttributes at;
-        if (hipFuncGetAttributes(&at, kv.func_desc) == hipSuccess) { if (at.localSizeBytes > 0) return remember(-1); }
-        else (void)hipGetLastError();
-    }
-    return remember(v);
-}
-Solution::LaunchPlan* Solution::get_launch_plan(int part, const bool* has_lo, const bool* has_hi, bool wide_shell, int mode) {
-    const KernelVariant& kv = impl.parts[part].variants[planned_variant_of(part)];
-    if (mode < 0) mode = (int)plan_mode;
-    std::ostringstream ks;
-    ks << part << ':' << planned_variant_of(part) << '/' << local_size[0] << 'x' << local_size[1] << 'x' << local_size[2] << '/';
-    for (int d = 0; d < 3; d++) ks << (has_lo[d] ? 'l' : '-') << (has_hi[d] ? 'h' : '-');
-    ks << '/' << shell_pct << '/' << mode << '/' << min_exterior << '/' << env->num_cus << '/' << (wide_shell ? wf_ext_[0] + wf_ext_[1] * 1000 + wf_ext_[2] * 1000000 : 0);
-    const std::string key = ks.str();
-    for (auto& lp : launch_plans) if (lp->key == key) return lp.get();
-    BlockPlanIn in;
-    for (int d = 0; d < 3; d++) {
-        in.n[d] = local_size[d]; in.has_lo[d] = has_lo[d]; in.has_hi[d] = has_hi[d];
-        // (what a neighbour needs of my boundary: the halo -- plus the wave-front extension in a multi-rank -Mbt group)
-        in.width[d] = std::max<idx_t>(std::max(shared_pad_l_[d], shared_pad_r_[d]) + (wide_shell ? wf_ext_[d] : 0), min_exterior);
-    }
-    in.ty = kv.ty; in.tz = kv.tz;
-    in.overhead = kv.xover > 0 ? kv.xover : std::max<idx_t>(1, shared_pad_r_[0] + 1);
-    in.ncu = std::max(1, env->num_cus);
-    in.shell_frac = (double)shell_pct / 100.0;
-    in.mode = mode;
-    auto lp = std::make_unique<LaunchPlan>();
-    lp->key = key;
-    try { lp->plan = plan_blocks(in); } catch (const PlanError& e) { YKH_THROW(e.what()); }
-    if (lp->plan.blocks.empty()) YKH_THROW("planned launch: empty plan");
-    YKH_HIP(hipMalloc(&lp->dev, lp->plan.blocks.size() * sizeof(BlockDesc)));
-    YKH_HIP(hipMemcpyAsync(lp->dev, lp->plan.blocks.data(), lp->plan.blocks.size() * sizeof(BlockDesc), hipMemcpyHostToDevice, compute_stream));
-    YKH_HIP(hipStreamSynchronize(compute_stream));
-    if (env->trace)
-        fprintf(stderr, "planned launch %s: %zu blocks (%lld signalling), simulated shell done at %lld, end at %lld, undivided %lld plane-iterations\n",
-                key.c_str(), lp->plan.blocks.size(), (long long)lp->plan.n_signal, (long long)lp->plan.shell_done,
-                (long long)lp->plan.makespan, (long long)lp->plan.undivided);
-    {
-        // where the shell ends: behind the last signalling block, rounded up to whole rounds of CUs (the blocks of a round end together)
-        size_t last = 0;
-        for (size_t i = 0; i < lp->plan.blocks.size(); i++) if (lp->plan.blocks[i].flags & BLOCK_SIGNALS) last = i + 1;
-        const size_t ncu = (size_t)std::max(1, env->num_cus);
-        lp->cut = std::min(lp->plan.blocks.size(), (last + ncu - 1) / ncu * ncu);
-        if (lp->plan.mode_used == 4) lp->cut = (size_t)lp->plan.cut;       // the two halves: the planner's own cut
-    }
-    launch_plans.push_back(std::move(lp));
-    return launch_plans.back().get();
-}
-void Solution::launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hipStream_t s, bool with_pack) {
-    const KernelVariant& kv = impl.parts[part].variants[planned_variant_of(part)];
-    if (lp.plan.mode_used == 4) {        // (the two halves back to back, without their exchanges: time_decomposed_step())
-        (void)with_pack;
-        launch_planned_half(part, t, lp, 0, s);
-        if (signal) { YKH_HIP(hipEventRecord(ev_shell, s)); shell_event_pending = true; }
-        launch_planned_half(part, t, lp, 1, s);
-        return;
-    }
-    PartArgs a;
-    fill_part_args(part, t, rank_box(), a);
-    a.blk = lp.dev;
-    if (signal && lp.plan.n_signal > 0 && planned_split) {
-        // two launches, an event between them (see planned_split): the shell's rounds, then the rest
-        kv.launch_desc(a, dim3((unsigned)lp.cut, 1, 1), s);
-        YKH_HIP(hipGetLastError());
-        if (with_pack && inline_pack) exchange_prepack(s);
-        YKH_HIP(hipEventRecord(ev_shell, s));
-        shell_event_pending = true;
-        if (lp.cut < lp.plan.blocks.size()) {
-            a.blk = lp.dev + lp.cut;
-            kv.launch_desc(a, dim3((unsigned)(lp.plan.blocks.size() - lp.cut), 1, 1), s);
-            YKH_HIP(hipGetLastError());
-        }
-        return;
-    }
-    if (signal && lp.plan.n_signal > 0) {
-        if (!sig_dev) {
-            // (zeroed before anything can poll it: a waiter on the comm stream must not read what hipMalloc left there)
-            YKH_HIP(hipMalloc(&sig_dev, 4 * sizeof(unsigned)));
-            YKH_HIP(hipMemsetAsync(sig_dev, 0, 4 * sizeof(unsigned), s));
-            YKH_HIP(hipStreamSynchronize(s));
-            sig_count = sig_epoch = 0;
-        }
-        sig_count += (unsigned)lp.plan.n_signal;
-        a.sig = sig_dev;
-        a.sig_goal = sig_count;
-        a.sig_epoch = ++sig_epoch;
-        sig_pending = true;
-        sig_used = true;
-    }
-    kv.launch_desc(a, dim3((unsigned)lp.plan.blocks.size(), 1, 1), s);
-    YKH_HIP(hipGetLastError());
-}
-
-// ------------------------------------------------------------------ pipelined half-exchanges (-hip_halves)
-// The reference keeps its MPI requests moving while it computes (adv_halo_exchange, src/kernel/lib/halo.cpp:494-574, called per
-// micro-block, context.cpp:1037-1040).  Planned launches (above) get their overlap from ORDER -- shell blocks first -- and pay for
-// it: tiles that march without their neighbours fetch the shared lines twice (1.05-1.13x the undivided sweep, DESIGN.md section
-// 4.1; the same blocks in regular order: 1.01-1.02x).  Here the order stays regular and the overlap comes from a software pipeline
-// over half-launches H0, H1, H2, ... (outer half A = [0, q1) u [q2, nx), inner half B = [q1, q2), A, B, ...):
-//     compute stream:  H_i            H_i+1                      H_i+2
-//     comm stream:            E_i: pack, send ... arrive, unpack --^ (H_i+2 waits for E_i; H_i+1 does not)
-// E_i carries what the neighbours need of H_i's planes: with face-only reads (l1_norm <= 1) the y / z halo a half reads lies in
-// that half's own planes, and the x faces lie in A.  Who needs E_i?  The next launch over the same planes, H_i+2 -- one whole
-// launch later.  Hazards: E_i's unpack writes halo cells of H_i's planes while H_i+1 runs; H_i+1 loads halo cells of its own
-// planes only (the marching kernels load prologue / tail planes without their halos, or never use them in a stored value), and
-// centre-only operands nowhere near a halo.  One exchange is in flight at a time: send / receive buffers and the transports'
-// per-exchange state are those of the whole-face path.
-bool Solution::halves_geometry(idx_t* q1, idx_t* q2) const {
-    if (ndd != 3 || has_outer || wf_multi()) return false;
-    return halves_split(local_size[0], std::max<idx_t>(1, std::max(shared_pad_l_[0], shared_pad_r_[0])), q1, q2);
-}
-bool Solution::halves_active() const {
-    if (!halves || !halves_geom_ok_ || !overlap_comms || !planned_launch || env->nranks <= 1 || !do_halo_exchange) return false;
-    if (std::max<idx_t>(mega_block_size[0], block_size[0]) > 1) return false;          // (wave-front groups exchange once per group)
-    for (int st = 0; st < meta->n_stages; st++)
-        if (planned_part(meta->stages[st]) < 0) return false;
-    return true;
-}
-void Solution::launch_planned_half(int part, idx_t t, LaunchPlan& lp, int half, hipStream_t s) {
-    const KernelVariant& kv = impl.parts[part].variants[planned_variant_of(part)];
-    const size_t first = half == 0 ? 0 : lp.cut, count = half == 0 ? lp.cut : lp.plan.blocks.size() - lp.cut;
-    if (count == 0) return;
-    PartArgs a;
-    fill_part_args(part, t, rank_box(), a);
-    a.blk = lp.dev + first;
-    kv.launch_desc(a, dim3((unsigned)count, 1, 1), s);
-    YKH_HIP(hipGetLastError());
-}
-// behind the launch of `half` (ev_shell has been recorded there): the comm stream waits for it, packs and sends that half's faces
-void Solution::halves_start(int half) {
-    exch_half_ = half;
-    shell_event_pending = true;
-    exchange_halos(0, 0, /*start_only=*/true, false);
-    exch_half_ = -1;
-    halves_in_flight_ = true;
-    halves_flight_half_ = half;
-    halves_flight_phase_ = cur_phase;
-}
-// the exchange in flight: the comm stream waits for its messages and unpacks them, the compute stream waits for the unpack --
-// i.e. whatever is launched AFTER this call sees the halos, what was launched before does not wait
-void Solution::halves_finish() {
-    if (!halves_in_flight_) return;
-    PhaseEvents* mine = cur_phase;
-    cur_phase = halves_flight_phase_;          // (transfer / unpack times belong to the phase set of the launch that produced the data)
-    exch_half_ = halves_flight_half_;
-    try { exchange_halos(0, 0, false, /*finish_only=*/true); } catch (...) { exch_half_ = -1; cur_phase = mine; halves_in_flight_ = false; throw; }
-    exch_half_ = -1;
-    cur_phase = mine;
-    halves_in_flight_ = false;
-    // (the inner half completes the faces: nothing is dirty any more -- also when this rank had no message in this exchange)
-    if (halves_flight_half_ == 1)
-        for (auto& v : vars) v->set_dirty_all(false);
-}
-void Solution::run_stage_halves(const StageMeta& sm, int /*st*/, idx_t t, const bool* has_lo, const bool* has_hi) {
-    const int part = planned_part(sm);
-    LaunchPlan* lp = get_launch_plan(part, has_lo, has_hi, false, /*mode=*/4);
-    for (int h = 0; h < 2; h++) {
-        cur_phase = phase_next();
-        phase_mark(PH_EXT0, compute_stream);
-        launch_planned_half(part, t, *lp, h, compute_stream);
-        YKH_HIP(hipEventRecord(ev_shell, compute_stream));
-        phase_mark(PH_INT1, compute_stream);
-        halves_finish();                       // the PREVIOUS half's exchange (its data are first read by the launch after this one)
-        phase_mark(PH_WAIT1, compute_stream);  // INT1 -> WAIT1: what the compute stream will idle behind this launch = exchange not hidden
-        // (host bookkeeping, after the previous stage's flags have been cleared: what this stage writes is dirty for both halves)
-        if (h == 0) note_stage_written(sm, t);
-        halves_start(h);                       // (marks EXT1 on the comm stream, behind its wait for this launch: EXT0 -> EXT1 = the launch)
-        cur_phase = nullptr;
-    }
-}
-
-// ------------------------------------------------------------------ phase timers
-// The reference times halo pack / unpack / wait and exterior / interior evaluation with host timers
-// (src/kernel/lib/context.hpp:319-328); here the phases are asynchronous, so each (step, stage) of a multi-rank run
-// gets HIP events on the stream the phase runs on; they are read once run() has drained the streams.
-Solution::PhaseEvents* Solution::phase_next() {
-    if (!phase_timers) return nullptr;
-    // A ring: run_solution(0, 99999) must not create 800 000 events.  Set number k of a run lives in slot k % PHASE_RING; before
-    // a slot is reused its times are folded into `stats` (its events are PHASE_RING stages old: the wait is almost never one).
-    const size_t slot = phase_used % PHASE_RING;
-    phase_pool.reserve(PHASE_RING);          // (sets are handed out by pointer, and the halves schedule holds two at a time: never re-allocate)
-    if (slot == phase_pool.size()) {
-        PhaseEvents ph;
-        for (int i = 0; i < PH_N; i++) { ph.e[i] = nullptr; ph.rec[i] = false; }
-        for (int i = 0; i < PH_N; i++) YKH_HIP(hipEventCreate(&ph.e[i]));
-        phase_pool.push_back(ph);
-    } else if (phase_used >= PHASE_RING) {
-        PhaseEvents& old = phase_pool[slot];
-        for (int i = 0; i < PH_N; i++) if (old.rec[i]) YKH_HIP(hipEventSynchronize(old.e[i]));
-        phase_fold(old);
-    }
-    phase_used++;
-    PhaseEvents* ph = &phase_pool[slot];
-    for (int i = 0; i < PH_N; i++) ph->rec[i] = false;
-    return ph;
-}
-void Solution::phase_mark(int which, hipStream_t st) {
-    if (!cur_phase) return;
-    YKH_HIP(hipEventRecord(cur_phase->e[which], st));
-    cur_phase->rec[which] = true;
-}
-void Solution::phase_fold(const PhaseEvents& ph) {
-    auto span = [&](int a, int b) -> double {
-        if (!ph.rec[a] || !ph.rec[b]) return 0.0;
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, ph.e[a], ph.e[b]) != hipSuccess) { (void)hipGetLastError(); return 0.0; }
-        return ms > 0 ? ms * 1e-3 : 0.0;
-    };
-    stats.exterior_secs += span(PH_EXT0, PH_EXT1);
-    stats.interior_secs += span(PH_EXT1, PH_INT1);
-    stats.halo_wait_secs += span(PH_INT1, PH_WAIT1);
-    const double pack = span(PH_PACK0, PH_PACK1), xfer = span(PH_PACK1, PH_XFER1), unpack = span(PH_XFER1, PH_UNPACK1);
-    stats.halo_pack_secs += pack; stats.halo_xfer_secs += xfer; stats.halo_unpack_secs += unpack;
-    stats.halo_secs += pack + xfer + unpack;
-}
-// (called when run() has drained the streams: every set still in the ring is complete)
-void Solution::phase_collect() {
-    const size_t live = std::min<size_t>(phase_used, phase_pool.size());
-    for (size_t i = 0; i < live; i++) phase_fold(phase_pool[i]);
-    for (auto& ph : phase_pool) for (int i = 0; i < PH_N; i++) ph.rec[i] = false;
-    phase_used = 0;
-}
-
-// ------------------------------------------------------------------ two steps per pass, fused on chip
-// Temporal blocking where the chip can hold it (ykh_starlin2.hpp): S(t+2) is computed from S(t) in
-// one sweep, S(t+1) stays in registers / LDS.  The kernel writes out of place, so the passes alternate between the
-// var's own slot and a scratch slot; the scratch starts as a copy of the slot (its pads are the slot's pads, which a
-// single rank never updates) and the layout is restored at the end.  The LAST pass also stores S(t+1), so that after
-// run_solution() both step slots hold what a plain run leaves there.
-bool Solution::can_fuse() const {
-    if (fuse_steps < 2 || env->nranks != 1 || ndd != 3 || force_scalar) return false;
-    if (impl.parts.size() != 1 || !impl.parts[0].fused2.launch || meta->n_stages != 1) return false;
-    const PartMeta& pm = *impl.parts[0].meta;
-    for (auto& v : vars)
-        if (v->meta == &meta->vars[pm.groups[0].var]) return v->nslots == 2 && v->is_allocated();
-    return false;
-}
-
-void Solution::launch_fused(idx_t t, const void* src, void* slot_b, void* dst, bool store_b) {
-    const Fused2Variant& f = impl.parts[0].fused2;
-    const Box rb = rank_box();
-    PartArgs a;
-    fill_part_args(0, t, rb, a);
-    a.ptr[0] = const_cast<void*>(src);
-    a.ptr[1] = slot_b;
-    a.ptr[2] = dst;
-    const idx_t zb = rb.lo[2] & ~(idx_t)(f.vz - 1);
-    a.ntz = (int)ceil_div(rb.hi[2] - zb, f.tzi);
-    a.nty = (int)ceil_div(rb.hi[1] - rb.lo[1], f.tyi);
-    const idx_t nx = rb.hi[0] - rb.lo[0], tiles = (idx_t)a.ntz * a.nty, cus = std::max(1, env->num_cus);
-    // x-chunks: fill the CUs in whole rounds; every chunk runs 4*xr+1 extra planes to fill the two pipelines
-    idx_t best_n = 1;
-    double best_eff = -1;
-    const idx_t extra = 4 * f.xr + 1;
-    for (idx_t n = 1; n <= 32; n++) {
-        idx_t len = ceil_div(nx, n);
-        if (n > 1 && len < 48) break;
-        idx_t blocks = tiles * ceil_div(nx, len);
-        double fill = (double)blocks / (double)(ceil_div(blocks, cus) * cus);
-        double eff = fill * (double)len / (double)(len + extra);
-        if (eff > best_eff * 1.02) { best_eff = eff; best_n = n; }
-    }
-    idx_t xc = xchunk_override > 0 ? xchunk_override : ceil_div(nx, best_n);
-    xc = std::max<idx_t>(1, std::min(xc, nx));
-    a.xchunk = (int)xc;
-    a.nxc = (int)ceil_div(nx, xc);
-    f.launch(a, dim3((unsigned)((idx_t)a.ntz * a.nty * a.nxc)), compute_stream, store_b);
-    YKH_HIP(hipGetLastError());
-}
-
-void Solution::run_fused(idx_t t0, idx_t npairs, idx_t dir) {
-    const PartMeta& pm = *impl.parts[0].meta;
-    Var* v = nullptr;
-    for (auto& vv : vars) if (vv->meta == &meta->vars[pm.groups[0].var]) v = vv.get();
-    if (!v) YKH_THROW("fused run: var not found");
-    const size_t slot_bytes = (size_t)v->slot_elems * elem_bytes(), org = (size_t)v->origin_elems * elem_bytes();
-    if (!v->scratch) YKH_HIP(hipMalloc(&v->scratch, slot_bytes));
-    char* slot_a = (char*)v->dptr + (size_t)v->slot_of(t0) * slot_bytes;            // holds S(t0), S(t0+2), ...
-    char* slot_b = (char*)v->dptr + (size_t)v->slot_of(t0 + dir) * slot_bytes;      // the in-between steps' slot
-    // The passes alternate between the slot and the scratch and must END in the slot.  Even number of passes: the scratch
-    // only needs the slot's pads (its domain is overwritten by the first pass).  Odd: the scratch becomes a full copy of
-    // the slot and the FIRST pass reads the copy and writes into the slot -- no copy back at the end either way.
-    idx_t alloc[3], padl[3], dom[3];
-    for (int d = 0; d < 3; d++) { padl[d] = v->pad_l[d]; dom[d] = v->dom_size[d]; alloc[d] = v->pad_l[d] + v->dom_size[d] + v->pad_r[d]; }
-    char* cur = slot_a;
-    char* other = (char*)v->scratch;
-    if (npairs % 2 == 0) launch_copy_pads(slot_a, v->scratch, elem_bytes(), alloc, padl, dom, compute_stream);
-    else {
-        YKH_HIP(hipMemcpyAsync(v->scratch, slot_a, slot_bytes, hipMemcpyDeviceToDevice, compute_stream));
-        std::swap(cur, other);
-    }
-    for (idx_t k = 0; k < npairs; k++) {
-        const idx_t t = t0 + dir * 2 * k;
-        launch_fused(t, cur + org, slot_b + org, other + org, /*store_b=*/k == npairs - 1);
-        std::swap(cur, other);
-        stats.fused_passes++;
-        v->update_valid_step(t + dir); v->update_valid_step(t + 2 * dir);
-    }
-    if (cur != slot_a) YKH_THROW("fused run: internal error (result is not in the var's slot)");
-    v->set_dirty_all(true);
-}
-
-// ------------------------------------------------------------------ wave-front temporal tiling
-// The reference's temporal wave-fronts (StencilContext::calc_mega_block / shift_mega_block, src/kernel/lib/context.cpp:
-// 482-745,1181-1525; angles from setup.cpp:863-1020) at launch granularity: the rank is cut into x-slabs; for one slab
-// after the other, phase p = (step, stage) number p of the group is evaluated on the slab shifted by -p * angle, where
-// angle = the widest x-halo of the solution.  Phase p+1 then finds every input it reads at x +- halo already computed by
-// phase p (this slab or an earlier one), and what it overwrites in place (2-slot write-back, 1-slot in-place vars) is
-// no longer needed by phase p of the next slab, whose reads start at x1 - p*angle - halo >= x1 - (p+1)*angle.
-// Every launch is an ordinary kernel launch over a box, so the result is bit-identical to plain sweeps.
-void Solution::run_wavefront(idx_t t0, idx_t nsteps, idx_t dir) {
-    const Box rb = rank_box();
-    const idx_t nx = rb.hi[0] - rb.lo[0];
-    const idx_t ang = std::max<idx_t>(1, std::max(shared_pad_l_[0], shared_pad_r_[0]));
-    const idx_t nphase = nsteps * meta->n_stages;
-    idx_t w = mega_block_size[1] > 0 ? mega_block_size[1] : 128;
-    w = std::max<idx_t>(w, ang);
-    for (const WavefrontLaunch& wl : plan_wavefront(rb.lo[0], rb.hi[0], w, ang, nphase)) {       // ykh_plan.cpp
-        const idx_t t = t0 + dir * (wl.phase / meta->n_stages);
-        const StageMeta& sm = meta->stages[wl.phase % meta->n_stages];
-        Box b = rb;
-        b.lo[0] = wl.lo;
-        b.hi[0] = wl.hi;
-        for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, b, compute_stream);
-    }
-    (void)nx;
-    // bookkeeping once per step: written vars become valid at the output step
-    for (idx_t s = 0; s < nsteps; s++) {
-        const idx_t t = t0 + dir * s;
-        for (int st = 0; st < meta->n_stages; st++) {
-            const StageMeta& sm = meta->stages[st];
-            for (int k = 0; k < sm.n_parts; k++) {
-                const PartMeta& pm = *impl.parts[sm.parts[k]].meta;
-                if (pm.is_scratch || (pm.step_cond && !pm.step_cond(t))) continue;
-                for (int wv = 0; wv < pm.n_writes; wv++) {
-                    const AccessGroup& ag = pm.groups[pm.writes[wv]];
-                    for (auto& v : vars)
-                        if (v->meta == &meta->vars[ag.var]) {
-                            if (ag.has_step) { v->update_valid_step(t + ag.dt); v->set_dirty(true, t + ag.dt); }
-                            else v->set_dirty_all(true);
-                        }
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------ wave-front tiling across ranks
-// The reference's temporal wave-fronts work across ranks by extending every rank's evaluation into its neighbours' domains
-// (left/right_wf_exts = angle x shifts, setup.cpp:717-805; the diagram in run_solution, context.cpp:286-346): the points
-// between "end (rank)" and "end (ext)" are computed by both ranks, and halos are exchanged once per group of -Mbt steps.
-// Here: a group of n steps is P = n x stages phases; phase p runs the stage's parts over the rank box grown by
-// wf_angle x (P-1-p) towards every side that has a neighbour.  Phase p+1's reads (reach: the halo = the angle) then lie
-// inside what phase p computed, the last phase covers exactly the rank box, and nothing has to travel inside the group.
-// The widened halos (wf_ext = angle x (P-1) beyond the stencil halo, all 26 neighbours: extended boxes have edges and
-// corners) are exchanged once per group -- half the messages per step at n = 2, against ~(1 + ext/size)^3 of redundant
-// arithmetic.  Every launch is an ordinary launch of the same kernel: bit-identical to plain multi-rank sweeps.
-// The last phase runs as a planned launch where the stage allows it (shell = what the neighbours need, now halo + wf_ext
-// wide, first; the exchange starts while the interior is still being computed).
-void Solution::run_wavefront_multi(idx_t t0, idx_t nsteps, idx_t dir, const bool* has_lo, const bool* has_hi, bool exchange) {
-    const idx_t nphase = nsteps * meta->n_stages;
-    const Box rb = rank_box();
-    for (idx_t p = 0; p < nphase; p++) {
-        const idx_t t = t0 + dir * (p / meta->n_stages);
-        const int st = (int)(p % meta->n_stages);
-        const StageMeta& sm = meta->stages[st];
-        const idx_t e = nphase - 1 - p;
-        Box b = rb;
-        for (int d = 0; d < ndd; d++) {
-            if (wf_ext_[d] <= 0) continue;
-            if (has_lo[d]) b.lo[d] -= wf_angle_[d] * e;
-            if (has_hi[d]) b.hi[d] += wf_angle_[d] * e;
-        }
-        const bool last = p == nphase - 1;
-        const int pl_part = (last && exchange && overlap_comms) ? planned_part(sm) : -1;
-        cur_phase = (exchange && last) ? phase_next() : nullptr;
-        if (pl_part >= 0) {
-            LaunchPlan* lp = get_launch_plan(pl_part, has_lo, has_hi, /*wide_shell=*/true);
-            phase_mark(PH_EXT0, compute_stream);
-            launch_planned(pl_part, t, *lp, /*signal=*/true, compute_stream);
-        } else {
-            phase_mark(PH_EXT1, compute_stream);
-            for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, b, compute_stream);
-        }
-        note_stage_written(sm, t);
-        if (last && exchange) {
-            exchange_halos(t, st, /*start_only=*/true, false);
-            phase_mark(PH_INT1, compute_stream);
-            exchange_halos(t, st, false, /*finish_only=*/true);
-            phase_mark(PH_WAIT1, compute_stream);
-        }
-        cur_phase = nullptr;
-    }
-}
-
 // ------------------------------------------------------------------ run
 // Coherency of the host copies behind get_raw_storage_buffer() around a call that uses and changes var data (ykh_var.cpp).
 struct RawStorageGuard {
@@ -1607,113 +890,6 @@ void Solution::note_stage_written(const StageMeta& sm, idx_t t) {
 }
 void Solution::note_step_written(idx_t t) {
     for (int st = 0; st < meta->n_stages; st++) note_stage_written(meta->stages[st], t);
-}
-
-// ------------------------------------------------------------------ captured step graphs
-// A single-rank run_solution(t0, t0 + N - 1) is N x (parts per step) kernel launches that depend on t only through the step
-// slots of their base pointers, i.e. the chain repeats every slot_period() steps.  Where a step is short (small rank boxes:
-// BASELINE config 1, 128^3 x 100 steps, is ~10 us of kernel per step) the host's launch calls and the gaps between dependent
-// dispatches are a large part of the step; the chain of G steps is captured once from the compute stream
-// (hipStreamBeginCapture around the very launches the plain loop issues), instantiated, cached, and replayed with one
-// hipGraphLaunch per G steps.  Results are bit-identical by construction (same kernels, same arguments, same order).
-// The reference has no counterpart (its steps are OpenMP regions); this is the launch-schedule side of calc_mega_block.
-idx_t Solution::slot_period() const {
-    auto gcd = [](idx_t a, idx_t b) { while (b) { idx_t r = a % b; a = b; b = r; } return a; };
-    idx_t p = 1;
-    for (auto& v : vars)
-        if (v->nslots > 1) p = p / gcd(p, v->nslots) * v->nslots;
-    for (auto& v : scratch_vars)
-        if (v->nslots > 1) p = p / gcd(p, v->nslots) * v->nslots;
-    return p;
-}
-bool Solution::step_graph_eligible() const {
-    if (env->nranks > 1 && do_halo_exchange && !neighbors.empty()) return false;
-    if (slot_period() > 16) return false;
-    for (auto& p : impl.parts) {
-        const PartMeta& pm = *p.meta;
-        // parts that run on some steps only, or whose arithmetic sees the step index: the chain is not periodic in t
-        if (pm.has_step_cond || pm.has_step_cond_dev || pm.uses_step_value) return false;       // (pm.step_cond is never null)
-    }
-    for (auto& v : vars)
-        if (v->raw_exposed()) return false;        // host copies are pushed / pulled around the launches
-    return true;
-}
-bool Solution::step_graph_wanted() const {
-    if (step_graphs == 0 || !step_graph_eligible()) return false;
-    if (step_graphs > 0) return true;
-    // default: rank boxes of up to 2^20 points, where a step is a few microseconds.  Measured (profiles/r03d_step_graphs, iso3dfd,
-    // 100 steps per call): 64^3 5.4 -> 4.8 us per step (+13 %); 128^3 (16 us per step) and everything larger: +-0.5 % -- queued
-    // stream launches are already issued ahead of the GPU, what is left between dependent dispatches is the GPU's own.
-    double pts = 1;
-    for (int d = 0; d < ndd; d++) pts *= (double)local_size[d];
-    if (has_outer) pts *= (double)local_size[3];
-    return pts <= 1048576.0;
-}
-std::string Solution::step_graph_key(idx_t t, idx_t dir, idx_t steps) const {
-    std::ostringstream os;
-    const idx_t P = slot_period();
-    os << ((t % P) + P) % P << '/' << dir << '/' << steps << '/' << round_launches << thin_slab_point_kernel << force_scalar;
-    for (size_t p = 0; p < part_variant.size(); p++) os << ',' << part_variant[p] << ':' << part_xchunk[p];
-    for (int d = 0; d < MAX_API_DOMAIN_DIMS; d++) os << ';' << local_size[d] << '+' << rank_ofs[d];
-    for (auto& v : vars) os << '|' << v->dptr << '.' << v->nslots;
-    for (auto& v : scratch_vars) os << '|' << v->dptr;
-    os << '@' << (void*)compute_stream;
-    return os.str();
-}
-void Solution::drop_step_graphs() {
-    for (auto& g : step_graph_cache) {
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        if (g.graph) (void)hipGraphDestroy(g.graph);
-    }
-    step_graph_cache.clear();
-}
-void Solution::issue_step(idx_t t) {
-    const Box rb = rank_box();
-    for (int st = 0; st < meta->n_stages; st++) {
-        const StageMeta& sm = meta->stages[st];
-        for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, rb, compute_stream);
-    }
-}
-Solution::StepGraph* Solution::get_step_graph(idx_t t, idx_t dir, idx_t steps) {
-    const std::string key = step_graph_key(t, dir, steps);
-    for (size_t i = 0; i < step_graph_cache.size(); i++)
-        if (step_graph_cache[i].key == key) {
-            if (i + 1 != step_graph_cache.size()) std::rotate(step_graph_cache.begin() + i, step_graph_cache.begin() + i + 1, step_graph_cache.end());
-            return &step_graph_cache.back();
-        }
-    StepGraph sg;
-    sg.key = key;
-    sg.steps = steps;
-    // (relaxed mode: neither other host threads -- a framework's allocator, a sampler -- nor this one -- a kernel's code object
-    //  loaded on its first launch -- are restricted in what they may call meanwhile; only launches on this stream are captured)
-    if (hipStreamBeginCapture(compute_stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;                   // e.g. a caller-supplied legacy stream: plain launches
-    }
-    try {
-        for (idx_t k = 0; k < steps; k++) issue_step(t + dir * k);
-    } catch (...) {
-        hipGraph_t g = nullptr;
-        (void)hipStreamEndCapture(compute_stream, &g);
-        if (g) (void)hipGraphDestroy(g);
-        (void)hipGetLastError();
-        throw;
-    }
-    if (hipStreamEndCapture(compute_stream, &sg.graph) != hipSuccess || !sg.graph) { (void)hipGetLastError(); return nullptr; }
-    size_t nn = 0;
-    if (hipGraphGetNodes(sg.graph, nullptr, &nn) == hipSuccess) sg.nodes = (idx_t)nn;
-    if (nn == 0 || hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        (void)hipGraphDestroy(sg.graph);
-        return nullptr;
-    }
-    if (step_graph_cache.size() >= 8) {   // least recently used out
-        (void)hipGraphExecDestroy(step_graph_cache.front().exec);
-        (void)hipGraphDestroy(step_graph_cache.front().graph);
-        step_graph_cache.erase(step_graph_cache.begin());
-    }
-    step_graph_cache.push_back(sg);
-    return &step_graph_cache.back();
 }
 
 void Solution::run(idx_t first_step, idx_t last_step) {
@@ -1929,107 +1105,6 @@ Stats Solution::get_stats() {
     s.pts_per_sec = s.elapsed_secs > 0 ? (double)pts * (double)s.num_steps_done / s.elapsed_secs : 0.0;
     stats = Stats();   // cleared on read, like the reference
     return s;
-}
-
-// ------------------------------------------------------------------ auto-tuner
-// The reference tunes CPU block sizes by timing steps (auto_tuner.cpp:206-434). Here the search
-// space is the list of compiled HIP tile shapes (x the x-march chunk); each candidate is timed on
-// scratch copies of the written step slots so that solution data is left untouched.
-void Solution::reset_auto_tuner(bool enable) { auto_tune = enable; }
-
-void Solution::run_auto_tuner_now() { tune_variants(false); }
-
-// quick: one pass with the default x-chunking, 1 warm-up + 3 timed launches per shape (used by prepare_solution() for
-// stencil libraries built by the generic registry, whose per-part defaults are a static guess).
-void Solution::tune_variants(bool quick) {
-    if (!prepared) YKH_THROW("run_auto_tuner_now() called without calling prepare_solution() first");
-    // events and var copies are released on every exit path (a failing launch throws)
-    struct Scratch {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        std::vector<void*> saves;
-        ~Scratch() {
-            for (auto p : saves) if (p) (void)hipFree(p);
-            if (e0) (void)hipEventDestroy(e0);
-            if (e1) (void)hipEventDestroy(e1);
-        }
-    } sc;
-    YKH_HIP(hipEventCreate(&sc.e0));
-    YKH_HIP(hipEventCreate(&sc.e1));
-    hipEvent_t e0 = sc.e0, e1 = sc.e1;
-    const Box rb = rank_box();
-    // save every var (tuning runs real kernels, which update written vars in place); when the copies would not
-    // fit the free device memory the current shapes are kept instead (288 GB hold one copy of a big problem, not two)
-    // Every decision below is agreed across ranks (max over ranks): all ranks time the same candidates in the same
-    // order and keep the same shape -- ranks running different shapes would differ in the last bits.
-    const bool many = env->nranks > 1;
-    {
-        size_t need = 0, free_b = 0, total_b = 0;
-        for (auto& v : vars)
-            if (v->is_allocated() && v->is_written) need += v->bytes();
-        long long skip = (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)need > 0.8 * (double)free_b) ? 1 : 0;
-        if (many) skip = env->max_over_ranks(skip);
-        if (skip) {
-            if (env->trace) fprintf(stderr, "auto-tuner: skipped, %zu bytes of var copies do not fit %zu free bytes\n", need, free_b);
-            return;
-        }
-    }
-    std::vector<void*>& saves = sc.saves;
-    saves.assign(vars.size(), nullptr);
-    for (size_t i = 0; i < vars.size(); i++)
-        if (vars[i]->is_allocated() && vars[i]->is_written) {
-            YKH_HIP(hipMalloc(&saves[i], vars[i]->bytes()));
-            YKH_HIP(hipMemcpyAsync(saves[i], vars[i]->dptr, vars[i]->bytes(), hipMemcpyDeviceToDevice, compute_stream));
-        }
-    for (size_t p = 0; p < impl.parts.size(); p++) {
-        const PartImpl& pi = impl.parts[p];
-        double best = 1e30;
-        int best_v = part_variant[p];
-        idx_t best_xc = part_xchunk[p];
-        long long pred = part_needs_predicate((int)p) ? 1 : 0;
-        if (many) pred = env->max_over_ranks(pred);
-        for (size_t k = 0; k < pi.variants.size(); k++) {
-            if (pred && k > 0) break;                                                          // only the point kernel is legal
-            if (force_scalar && k > 0) break;
-            if (std::strncmp(pi.variants[k].name, "abl", 3) == 0) continue;                   // profiling ablations
-            if (variant_scratch_bytes(pi.variants[k]) > 0) continue;                          // spilled registers
-            if (!fast_div && std::strstr(pi.variants[k].name, "_fd")) continue;               // -no-hip_fast_div: exact divisions only
-            std::vector<idx_t> chunks = {0};
-            if (pi.variants[k].star && pi.variants[k].rx == 0 && !quick) { chunks.push_back(rb.hi[0] - rb.lo[0]); chunks.push_back(256); chunks.push_back(128); }
-            for (idx_t xc : chunks) {
-                launch_part_variant((int)p, (int)k, xc, 0, rb, compute_stream);   // warm-up
-                YKH_HIP(hipEventRecord(e0, compute_stream));
-                int reps = 0;
-                float ms = 0;
-                do {
-                    launch_part_variant((int)p, (int)k, xc, 0, rb, compute_stream);
-                    reps++;
-                    YKH_HIP(hipEventRecord(e1, compute_stream));
-                    YKH_HIP(hipEventSynchronize(e1));
-                    YKH_HIP(hipEventElapsedTime(&ms, e0, e1));
-                } while (quick ? reps < 3 : (ms * 1e-3 < auto_tune_trial_secs && reps < 50));
-                double per = ms / reps;
-                if (many) per = (double)env->max_over_ranks((long long)(per * 1e6)) * 1e-6;      // the slowest rank's time, in ns
-                if (env->trace) fprintf(stderr, "auto-tuner: part %s variant %s xchunk %lld: %.4f ms\n", pi.meta->name,
-                                        pi.variants[k].name, (long long)xc, per);
-                if (per < best) { best = per; best_v = (int)k; best_xc = xc; }
-            }
-        }
-        part_variant[p] = best_v;
-        part_xchunk[p] = best_xc;
-    }
-    for (size_t i = 0; i < vars.size(); i++)
-        if (saves[i]) {
-            YKH_HIP(hipMemcpyAsync(vars[i]->dptr, saves[i], vars[i]->bytes(), hipMemcpyDeviceToDevice, compute_stream));
-        }
-    YKH_HIP(hipStreamSynchronize(compute_stream));
-    drop_launch_plans();          // (the kernel shapes may have changed)
-}
-
-idx_t Solution::compare_data(const Solution& ref, double eps) const {
-    idx_t bad = 0;
-    if (vars.size() != ref.vars.size()) return 1;
-    for (size_t i = 0; i < vars.size(); i++) bad += vars[i]->compare(*ref.vars[i], eps);
-    return bad;
 }
 
 }  // namespace ykh

@@ -1,0 +1,327 @@
+// ykh_tune.cpp -- what prepare_solution() and the tuner decide by MEASUREMENT (part of class Solution, split off
+// ykh_solution.cpp in round 4): placement of the var allocations, captured step graphs, and the auto-tuner over the compiled
+// tile shapes (the reference's AutoTuner, src/kernel/lib/auto_tuner.cpp:206-586).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+
+#include "ykh_runtime.hpp"
+#include "ykh_solution_internal.hpp"
+
+namespace ykh {
+
+// ------------------------------------------------------------------ var placement
+// A stencil kernel streams several arrays at the same logical position at the same time; where those arrays lie in physical
+// memory -- relative to each other and absolutely -- decides how often the streams meet in a DRAM channel or bank.  Measured
+// (tools/placement_probe.py, profiles/r03h_placement): the same kernel in the same process runs 3-4 % apart on two sets of
+// freshly allocated arrays (iso3dfd 1024^3: 2.88 ... 3.03 ms per step, ssg 512^3: 2.78 ... 2.98), each set stable to 0.1 %.
+// 256-byte skews of the bases do not control it, and neither does one shared allocation with chosen spacings (the reference's
+// -bundle_allocs, alloc.cpp:343-452: measured here, ssg then runs uniformly at the slow end) -- the address hash takes high
+// bits.  What works is what the numbers say: draw several placements, time a step on each, keep the fastest.  That is done
+// once, in prepare_solution(), while the arrays are still empty: every further set is allocated WHILE the best one so far is
+// held (so the allocator must hand out other memory), a few steps are timed on it, and the loser is freed.
+void Solution::tune_placement() {
+    placement_ms.clear();
+    placement_chosen = 0;
+    if (impl.parts.empty()) return;
+    for (size_t p = 0; p < impl.parts.size(); p++) if (part_variant[p] < 0) return;
+    std::vector<Var*> mv;
+    size_t total = 0;
+    for (auto& v : vars) if (!v->fixed_size && v->is_allocated() && !v->fuse_group) { mv.push_back(v.get()); total += v->bytes(); }
+    for (auto& v : scratch_vars) if (v->is_allocated()) { mv.push_back(v.get()); total += v->bytes(); }
+    if (mv.empty()) return;
+    struct Ev {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Ev() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev;
+    YKH_HIP(hipEventCreate(&ev.e0));
+    YKH_HIP(hipEventCreate(&ev.e1));
+    const Box rb = rank_box();
+    auto time_steps = [&]() -> float {
+        // O(1) hashed values, no zeros (timed on zeroed arrays the ranking did not hold: all-zero data runs ~3 % faster)
+        for (size_t k = 0; k < mv.size(); k++) mv[k]->set_elements_hash(1.0, 0.1, (int)k);
+        float ms_min = 0.f;
+        for (int r = 0; r <= 3; r++) {                 // r = 0: untimed (first touch of the new addresses)
+            YKH_HIP(hipEventRecord(ev.e0, compute_stream));
+            for (int st = 0; st < meta->n_stages; st++)
+                for (int k = 0; k < meta->stages[st].n_parts; k++) launch_part(meta->stages[st].parts[k], r, rb, compute_stream);
+            YKH_HIP(hipEventRecord(ev.e1, compute_stream));
+            YKH_HIP(hipEventSynchronize(ev.e1));
+            float ms = 0.f;
+            YKH_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+            if (r > 0 && (ms_min == 0.f || ms < ms_min)) ms_min = ms;
+        }
+        return ms_min;
+    };
+    // a set of allocations = (owner, alloc_ptr, dptr) per var; the vars always point at the set being timed; a set nobody
+    // points at any more is freed when its owners go (Var::own_allocation)
+    struct PlacedVar { std::shared_ptr<void> own; void* alloc; void* data; };
+    typedef std::vector<PlacedVar> PtrSet;
+    auto current = [&]() { PtrSet s; for (auto* v : mv) s.push_back({v->alloc_owner, v->alloc_ptr, v->dptr}); return s; };
+    auto attach = [&](const PtrSet& s) { for (size_t k = 0; k < mv.size(); k++) mv[k]->adopt_storage(s[k].own, s[k].alloc, s[k].data, mv[k]->alloc_bytes); };
+    auto free_set = [&](PtrSet& s) { s.clear(); };
+    PtrSet best = current();
+    // A GPU that idled is still raising its clocks: step until the step time has settled (three groups of steps within 0.5 %,
+    // 1 s at most) -- otherwise the sets timed later simply look faster (seen on a cold box: the "best" set then ran 4 % slower
+    // than it had measured).  And every candidate is compared with the incumbent timed right before it, not with a number from
+    // earlier.
+    {
+        float g[3] = {0.f, 0.f, 0.f};
+        const auto w0 = std::chrono::steady_clock::now();
+        for (int it = 0; it < 200; it++) {
+            g[it % 3] = time_steps();
+            const float lo = std::min({g[0], g[1], g[2]}), hi = std::max({g[0], g[1], g[2]});
+            if (it >= 2 && lo > 0.f && hi - lo <= std::max(lo * 0.005f, 0.004f)) break;      // (short steps: 4 us of timer noise)
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() > 1.0) break;
+        }
+    }
+    float best_ms = time_steps();
+    placement_ms.push_back(best_ms);
+    for (idx_t trial = 1; trial < placement_trials; trial++) {
+        size_t free_b = 0, tot_b = 0;
+        if (hipMemGetInfo(&free_b, &tot_b) != hipSuccess) { (void)hipGetLastError(); break; }
+        if ((double)free_b < 1.25 * (double)total + (double)((size_t)1 << 30)) break;      // no room for another set
+        PtrSet cand;
+        bool ok = true;
+        for (auto* v : mv) {
+            const size_t skew = (size_t)((char*)v->dptr - (char*)v->alloc_ptr), nb = std::max<size_t>(v->bytes(), 256);
+            void* p = nullptr;
+            if (hipMalloc(&p, nb + skew) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+            cand.push_back({Var::own_allocation(p), p, (char*)p + skew});
+            if (hipMemsetAsync((char*)p + skew, 0, nb, compute_stream) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+        }
+        if (!ok) { free_set(cand); break; }
+        float ms = 0.f, inc = 0.f;
+        try {
+            inc = time_steps();                  // the incumbent, now
+            attach(cand);
+            ms = time_steps();
+        } catch (...) { attach(best); free_set(cand); throw; }
+        placement_ms.push_back(ms);
+        if (ms < inc) { free_set(best); best = cand; best_ms = ms; placement_chosen = (int)placement_ms.size() - 1; }
+        else { attach(best); free_set(cand); best_ms = inc; }
+    }
+    attach(best);
+    // the trial data and results go: back to the zeros a fresh allocation holds
+    for (auto* v : mv) YKH_HIP(hipMemsetAsync(v->dptr, 0, std::max<size_t>(v->bytes(), 256), compute_stream));
+    YKH_HIP(hipStreamSynchronize(compute_stream));
+}
+
+// ------------------------------------------------------------------ captured step graphs
+// A single-rank run_solution(t0, t0 + N - 1) is N x (parts per step) kernel launches that depend on t only through the step
+// slots of their base pointers, i.e. the chain repeats every slot_period() steps.  Where a step is short (small rank boxes:
+// BASELINE config 1, 128^3 x 100 steps, is ~10 us of kernel per step) the host's launch calls and the gaps between dependent
+// dispatches are a large part of the step; the chain of G steps is captured once from the compute stream
+// (hipStreamBeginCapture around the very launches the plain loop issues), instantiated, cached, and replayed with one
+// hipGraphLaunch per G steps.  Results are bit-identical by construction (same kernels, same arguments, same order).
+// The reference has no counterpart (its steps are OpenMP regions); this is the launch-schedule side of calc_mega_block.
+idx_t Solution::slot_period() const {
+    auto gcd = [](idx_t a, idx_t b) { while (b) { idx_t r = a % b; a = b; b = r; } return a; };
+    idx_t p = 1;
+    for (auto& v : vars)
+        if (v->nslots > 1) p = p / gcd(p, v->nslots) * v->nslots;
+    for (auto& v : scratch_vars)
+        if (v->nslots > 1) p = p / gcd(p, v->nslots) * v->nslots;
+    return p;
+}
+bool Solution::step_graph_eligible() const {
+    if (env->nranks > 1 && do_halo_exchange && !neighbors.empty()) return false;
+    if (slot_period() > 16) return false;
+    for (auto& p : impl.parts) {
+        const PartMeta& pm = *p.meta;
+        // parts that run on some steps only, or whose arithmetic sees the step index: the chain is not periodic in t
+        if (pm.has_step_cond || pm.has_step_cond_dev || pm.uses_step_value) return false;       // (pm.step_cond is never null)
+    }
+    for (auto& v : vars)
+        if (v->raw_exposed()) return false;        // host copies are pushed / pulled around the launches
+    return true;
+}
+bool Solution::step_graph_wanted() const {
+    if (step_graphs == 0 || !step_graph_eligible()) return false;
+    if (step_graphs > 0) return true;
+    // default: rank boxes of up to 2^20 points, where a step is a few microseconds.  Measured (profiles/r03d_step_graphs, iso3dfd,
+    // 100 steps per call): 64^3 5.4 -> 4.8 us per step (+13 %); 128^3 (16 us per step) and everything larger: +-0.5 % -- queued
+    // stream launches are already issued ahead of the GPU, what is left between dependent dispatches is the GPU's own.
+    double pts = 1;
+    for (int d = 0; d < ndd; d++) pts *= (double)local_size[d];
+    if (has_outer) pts *= (double)local_size[3];
+    return pts <= 1048576.0;
+}
+std::string Solution::step_graph_key(idx_t t, idx_t dir, idx_t steps) const {
+    std::ostringstream os;
+    const idx_t P = slot_period();
+    os << ((t % P) + P) % P << '/' << dir << '/' << steps << '/' << round_launches << thin_slab_point_kernel << force_scalar;
+    for (size_t p = 0; p < part_variant.size(); p++) os << ',' << part_variant[p] << ':' << part_xchunk[p];
+    for (int d = 0; d < MAX_API_DOMAIN_DIMS; d++) os << ';' << local_size[d] << '+' << rank_ofs[d];
+    for (auto& v : vars) os << '|' << v->dptr << '.' << v->nslots;
+    for (auto& v : scratch_vars) os << '|' << v->dptr;
+    os << '@' << (void*)compute_stream;
+    return os.str();
+}
+// Var::allocate / release / fuse_with: a transport that cached the address (or the IPC handle) of a var's planes must not use it
+// again -- a new allocation can land on the very same base address.  Collective by nature of the API (every rank
+// manages its storage the same way); the transport re-registers at the next exchange (exch_begin agrees on it across ranks).
+void Solution::note_storage_changed() {
+    if (env && env->nranks > 1 && env->exch_reset) env->exch_reset(env->user);
+}
+void Solution::drop_step_graphs() {
+    for (auto& g : step_graph_cache) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    step_graph_cache.clear();
+}
+void Solution::issue_step(idx_t t) {
+    const Box rb = rank_box();
+    for (int st = 0; st < meta->n_stages; st++) {
+        const StageMeta& sm = meta->stages[st];
+        for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, rb, compute_stream);
+    }
+}
+Solution::StepGraph* Solution::get_step_graph(idx_t t, idx_t dir, idx_t steps) {
+    const std::string key = step_graph_key(t, dir, steps);
+    for (size_t i = 0; i < step_graph_cache.size(); i++)
+        if (step_graph_cache[i].key == key) {
+            if (i + 1 != step_graph_cache.size()) std::rotate(step_graph_cache.begin() + i, step_graph_cache.begin() + i + 1, step_graph_cache.end());
+            return &step_graph_cache.back();
+        }
+    StepGraph sg;
+    sg.key = key;
+    sg.steps = steps;
+    // (relaxed mode: neither other host threads -- a framework's allocator, a sampler -- nor this one -- a kernel's code object
+    //  loaded on its first launch -- are restricted in what they may call meanwhile; only launches on this stream are captured)
+    if (hipStreamBeginCapture(compute_stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;                   // e.g. a caller-supplied legacy stream: plain launches
+    }
+    try {
+        for (idx_t k = 0; k < steps; k++) issue_step(t + dir * k);
+    } catch (...) {
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(compute_stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        throw;
+    }
+    if (hipStreamEndCapture(compute_stream, &sg.graph) != hipSuccess || !sg.graph) { (void)hipGetLastError(); return nullptr; }
+    size_t nn = 0;
+    if (hipGraphGetNodes(sg.graph, nullptr, &nn) == hipSuccess) sg.nodes = (idx_t)nn;
+    if (nn == 0 || hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipGraphDestroy(sg.graph);
+        return nullptr;
+    }
+    if (step_graph_cache.size() >= 8) {   // least recently used out
+        (void)hipGraphExecDestroy(step_graph_cache.front().exec);
+        (void)hipGraphDestroy(step_graph_cache.front().graph);
+        step_graph_cache.erase(step_graph_cache.begin());
+    }
+    step_graph_cache.push_back(sg);
+    return &step_graph_cache.back();
+}
+
+// ------------------------------------------------------------------ auto-tuner
+// The reference tunes CPU block sizes by timing steps (auto_tuner.cpp:206-434). Here the search
+// space is the list of compiled HIP tile shapes (x the x-march chunk); each candidate is timed on
+// scratch copies of the written step slots so that solution data is left untouched.
+void Solution::reset_auto_tuner(bool enable) { auto_tune = enable; }
+
+void Solution::run_auto_tuner_now() { tune_variants(false); }
+
+// quick: one pass with the default x-chunking, 1 warm-up + 3 timed launches per shape (used by prepare_solution() for
+// stencil libraries built by the generic registry, whose per-part defaults are a static guess).
+void Solution::tune_variants(bool quick) {
+    if (!prepared) YKH_THROW("run_auto_tuner_now() called without calling prepare_solution() first");
+    // events and var copies are released on every exit path (a failing launch throws)
+    struct Scratch {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        std::vector<void*> saves;
+        ~Scratch() {
+            for (auto p : saves) if (p) (void)hipFree(p);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } sc;
+    YKH_HIP(hipEventCreate(&sc.e0));
+    YKH_HIP(hipEventCreate(&sc.e1));
+    hipEvent_t e0 = sc.e0, e1 = sc.e1;
+    const Box rb = rank_box();
+    // save every var (tuning runs real kernels, which update written vars in place); when the copies would not
+    // fit the free device memory the current shapes are kept instead (288 GB hold one copy of a big problem, not two)
+    // Every decision below is agreed across ranks (max over ranks): all ranks time the same candidates in the same
+    // order and keep the same shape -- ranks running different shapes would differ in the last bits.
+    const bool many = env->nranks > 1;
+    {
+        size_t need = 0, free_b = 0, total_b = 0;
+        for (auto& v : vars)
+            if (v->is_allocated() && v->is_written) need += v->bytes();
+        long long skip = (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)need > 0.8 * (double)free_b) ? 1 : 0;
+        if (many) skip = env->max_over_ranks(skip);
+        if (skip) {
+            if (env->trace) fprintf(stderr, "auto-tuner: skipped, %zu bytes of var copies do not fit %zu free bytes\n", need, free_b);
+            return;
+        }
+    }
+    std::vector<void*>& saves = sc.saves;
+    saves.assign(vars.size(), nullptr);
+    for (size_t i = 0; i < vars.size(); i++)
+        if (vars[i]->is_allocated() && vars[i]->is_written) {
+            YKH_HIP(hipMalloc(&saves[i], vars[i]->bytes()));
+            YKH_HIP(hipMemcpyAsync(saves[i], vars[i]->dptr, vars[i]->bytes(), hipMemcpyDeviceToDevice, compute_stream));
+        }
+    for (size_t p = 0; p < impl.parts.size(); p++) {
+        const PartImpl& pi = impl.parts[p];
+        double best = 1e30;
+        int best_v = part_variant[p];
+        idx_t best_xc = part_xchunk[p];
+        long long pred = part_needs_predicate((int)p) ? 1 : 0;
+        if (many) pred = env->max_over_ranks(pred);
+        for (size_t k = 0; k < pi.variants.size(); k++) {
+            if (pred && k > 0) break;                                                          // only the point kernel is legal
+            if (force_scalar && k > 0) break;
+            if (std::strncmp(pi.variants[k].name, "abl", 3) == 0) continue;                   // profiling ablations
+            if (variant_scratch_bytes(pi.variants[k]) > 0) continue;                          // spilled registers
+            if (!fast_div && std::strstr(pi.variants[k].name, "_fd")) continue;               // -no-hip_fast_div: exact divisions only
+            std::vector<idx_t> chunks = {0};
+            if (pi.variants[k].star && pi.variants[k].rx == 0 && !quick) { chunks.push_back(rb.hi[0] - rb.lo[0]); chunks.push_back(256); chunks.push_back(128); }
+            for (idx_t xc : chunks) {
+                launch_part_variant((int)p, (int)k, xc, 0, rb, compute_stream);   // warm-up
+                YKH_HIP(hipEventRecord(e0, compute_stream));
+                int reps = 0;
+                float ms = 0;
+                do {
+                    launch_part_variant((int)p, (int)k, xc, 0, rb, compute_stream);
+                    reps++;
+                    YKH_HIP(hipEventRecord(e1, compute_stream));
+                    YKH_HIP(hipEventSynchronize(e1));
+                    YKH_HIP(hipEventElapsedTime(&ms, e0, e1));
+                } while (quick ? reps < 3 : (ms * 1e-3 < auto_tune_trial_secs && reps < 50));
+                double per = ms / reps;
+                if (many) per = (double)env->max_over_ranks((long long)(per * 1e6)) * 1e-6;      // the slowest rank's time, in ns
+                if (env->trace) fprintf(stderr, "auto-tuner: part %s variant %s xchunk %lld: %.4f ms\n", pi.meta->name,
+                                        pi.variants[k].name, (long long)xc, per);
+                if (per < best) { best = per; best_v = (int)k; best_xc = xc; }
+            }
+        }
+        part_variant[p] = best_v;
+        part_xchunk[p] = best_xc;
+    }
+    for (size_t i = 0; i < vars.size(); i++)
+        if (saves[i]) {
+            YKH_HIP(hipMemcpyAsync(vars[i]->dptr, saves[i], vars[i]->bytes(), hipMemcpyDeviceToDevice, compute_stream));
+        }
+    YKH_HIP(hipStreamSynchronize(compute_stream));
+    drop_launch_plans();          // (the kernel shapes may have changed)
+}
+
+idx_t Solution::compare_data(const Solution& ref, double eps) const {
+    idx_t bad = 0;
+    if (vars.size() != ref.vars.size()) return 1;
+    for (size_t i = 0; i < vars.size(); i++) bad += vars[i]->compare(*ref.vars[i], eps);
+    return bad;
+}
+
+}  // namespace ykh

@@ -168,8 +168,20 @@ std::shared_ptr<void> Var::own_allocation(void* alloc) {
 // The storage of this var -- and of every var fused with it -- becomes [data, data + nbytes) inside `alloc`.
 void Var::adopt_storage(std::shared_ptr<void> owner, void* alloc, void* data, size_t nbytes) {
     auto set = [&](Var& m) { m.alloc_owner = owner; m.alloc_ptr = alloc; m.dptr = data; m.alloc_bytes = nbytes; };
-    if (fuse_group) for (Var* m : *fuse_group) set(*m);
-    else set(*this);
+    if (fuse_group) {
+        // Vars fused while unprepared may have ended up with different geometry (pads / sizes of their own solutions): every
+        // member indexes this ONE allocation with its own strides, so all of them must describe the same layout -- the
+        // reference demands identical layouts when it fuses into a solution var (yk_var_apis.cpp:344-351).  ADVICE r03.
+        for (Var* m : *fuse_group) {
+            if (m == this || !m->soln->prepared) continue;      // (a member whose solution is not prepared yet has no geometry of its own so far)
+            bool same = m->nslots == nslots && m->slot_elems == slot_elems && m->origin_elems == origin_elems && m->bytes() == bytes();
+            for (int d = 0; d < MAX_DOMAIN_DIMS && same; d++) same = m->stride[d] == stride[d] && m->pad_l[d] == pad_l[d] && m->dom_size[d] == dom_size[d];
+            if (!same)
+                YKH_THROW("fuse_vars: storage layouts of the fused vars '" + name + "' and '" + m->name + "' differ (their solutions gave them different "
+                          "sizes or pads after they were fused): they cannot share one allocation");
+        }
+        for (Var* m : *fuse_group) set(*m);
+    } else set(*this);
 }
 void Var::drop_storage_refs() {
     alloc_owner.reset();
@@ -197,6 +209,8 @@ void Var::fuse_with(Var& src) {
     alloc_owner = src.alloc_owner; alloc_ptr = src.alloc_ptr; dptr = src.dptr; alloc_bytes = src.alloc_bytes;
     first_valid_step = src.first_valid_step;
     dirty = src.dirty;
+    dirty.resize((size_t)std::max(1, nslots), 1);       // (flags are indexed by MY slots; a longer or shorter source must not be read past its end)
+    soln->note_storage_changed();
 }
 
 void Var::allocate() {
@@ -215,12 +229,15 @@ void Var::allocate() {
     // allocation while the first init kernel had already written it (seen at >= 512^3).
     YKH_HIP(hipMemsetAsync(dptr, 0, nb, soln->compute_stream));
     YKH_HIP(hipStreamSynchronize(soln->compute_stream));
+    soln->note_storage_changed();
 }
 
 // release_storage(): "after fusing, calling release_storage() on this var or the source var will apply to both"
 void Var::release() {
+    const bool had = dptr != nullptr;
     if (fuse_group) for (Var* m : *fuse_group) m->drop_storage_refs();
     else drop_storage_refs();
+    if (had) soln->note_storage_changed();
 }
 
 int Var::slot_of(idx_t t) const { return has_step ? (int)imod_flr(t, nslots) : 0; }

@@ -533,6 +533,12 @@ class yk_env:
     def disable_debug_output(): yk_env._debug = yask_output_factory().new_null_output()
 
     # ---- multi-GPU set-up (one process per GPU)
+    def get_device_bus_id(self):
+        """PCI bus id of the device this process computes on."""
+        buf = C.create_string_buffer(64)
+        self._lib.call("yk_env_get_device_bus_id", self._h, buf, 64)
+        return buf.value.decode()
+
     def set_ranks(self, rank, num_ranks): self._lib.call_rc("yk_env_set_ranks", self._h, int(rank), int(num_ranks))
 
     def set_transport(self, start, wait, allreduce):
@@ -569,6 +575,13 @@ class yk_env:
     def transport_loopback(self, nbytes=1 << 22):
         """Run the installed halo transport once with this rank as its own peer and verify the bytes."""
         self._lib.call_rc("yk_env_transport_loopback", self._h, int(nbytes))
+
+    def get_transport_counters(self):
+        """Control-plane counters of the installed halo transport (yk_env_get_transport_counters); {} when it keeps none."""
+        buf = (C.c_longlong * 8)()
+        n = int(self._lib.call("yk_env_get_transport_counters", self._h, buf, 8))
+        names = ("ctl_msgs", "ctl_bytes", "begins", "resets", "dev_ops", "mailbox_kind")
+        return {k: int(buf[i]) for i, k in enumerate(names[:max(n, 0)])}
 
     def probe_bandwidth(self, kind=1, nbytes=1 << 30, reps=3):
         """GB/s a 16-byte-per-lane streaming kernel gets on this device now: kind 0 copy, 1 three reads + one write, 2 read."""
