@@ -183,11 +183,12 @@ def _num(tok):
     return float(tok[:-1]) * mult[tok[-1]] if tok[-1] in mult else float(tok)
 
 
-def _ref_harness(exe, n, steps, trials, threads, timeout):
+def _ref_harness(exe, n, steps, trials, threads, timeout, tuned=False):
     """The reference's own harness (src/kernel/yask_main.cpp, built unmodified by oracle/Makefile): best and mid
-    (50th-percentile) throughput over `trials` trials, as SURVEY.md section 8(d) asks; default (DSL) block sizes."""
-    cmd = [str(exe), "-g", str(n), "-trial_steps", str(steps), "-num_trials", str(trials), "-no-pre_auto_tune", "-no-auto_tune",
-           "-outer_threads", str(threads), "-sleep", "0"]
+    (50th-percentile) throughput over `trials` trials, as SURVEY.md section 8(d) asks; default (DSL) block sizes, or -- tuned --
+    the block sizes its auto-tuner settles on before the trials (-pre_auto_tune, the reference's own default)."""
+    cmd = [str(exe), "-g", str(n), "-trial_steps", str(steps), "-num_trials", str(trials)] + \
+          (["-pre_auto_tune"] if tuned else ["-no-pre_auto_tune", "-no-auto_tune"]) + ["-outer_threads", str(threads), "-sleep", "0"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd="/tmp")
     res = {}
     for line in out.stdout.splitlines():
@@ -218,13 +219,29 @@ def cpu_baseline():
                 r = _ref_harness(exe, n, 10, 3, cores, 300)
             secs = time.time() - t0
             c1 = _ref_harness(exe, 128, 100, 3, cores, 120)
+            # the tuned headline next to the reproducible no-tune one -- the reference's auto-tuner picks
+            # its block sizes first, then 2 trials x 50 steps; bounded: skipped when the no-tune run says it
+            # would take minutes on this host
+            tuned = None
+            if "best" in r and r["best"] >= 2.0:
+                try:
+                    t1 = time.time()
+                    tr = _ref_harness(exe, n, 50, 2, cores, 300, tuned=True)
+                    if "best" in tr:
+                        tuned = {"best": round(tr["best"], 4), "mid": round(tr.get("mid", tr["best"]), 4), "secs_incl_tuning": round(time.time() - t1, 1),
+                                 "what": f"-pre_auto_tune, 2 trials x 50 steps, {n}^3"}
+                except Exception as e:  # noqa: BLE001
+                    tuned = {"error": repr(e)[:200]}
             if "best" in r:
-                return {"value": round(r["best"], 4), "unit": "Gpoints/s", "cores": cores, "kind": "reference",
+                best_of = max(r["best"], (tuned or {}).get("best", 0.0) or 0.0)
+                return {"value": round(best_of, 4), "unit": "Gpoints/s", "cores": cores, "kind": "reference",
+                        "no_tune_best": round(r["best"], 4), "auto_tuned": tuned,
                         "mid": round(r.get("mid", r["best"]), 4),
                         "c1_128cubed_100steps": {"best": round(c1.get("best", 0.0), 4), "mid": round(c1.get("mid", 0.0), 4)},
                         "sample": f"iso3dfd r=8 fp32 {n}^3 ({'the headline grid' if n == 1024 else '1/8 of the headline grid: host RAM short'}), "
                                   f"3 trials x 10 steps, best + mid (50th percentile) of the reference's own harness "
-                                  f"(yask_kernel.iso3dfd.{arch}.exe -no-pre_auto_tune -no-auto_tune -outer_threads {cores}), "
+                                  f"(yask_kernel.iso3dfd.{arch}.exe -no-pre_auto_tune -no-auto_tune -outer_threads {cores}); value = the better of that "
+                                  f"and the auto-tuned run (auto_tuned), "
                                   f"{secs:.0f} s incl. allocation; {os.cpu_count()} logical CPUs visible, {cores} usable (affinity / cgroup quota)"}
         except Exception as e:  # noqa: BLE001
             print("cpu_baseline: reference run failed:", e, file=sys.stderr)
@@ -330,6 +347,9 @@ def main():
     import torch
     from yask_amd import yk_factory, dist as ydist
 
+    if os.environ.get("YASK_BENCH_STACK_DUMP_S"):      # debugging aid: where is every rank after so many seconds?
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["YASK_BENCH_STACK_DUMP_S"]), repeat=False, file=sys.stderr)
     rank, local_rank, world = ydist.init_process_group()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -417,6 +437,7 @@ def main():
                 f, l = so.get_first_rank_domain_index_vec(), so.get_last_rank_domain_index_vec()
                 boxes = (f, l, {nm: so.get_var(nm).get_elements_in_slice([steps_c] + f, [steps_c] + l)[0] for nm in fields})
                 so.end_solution()
+                del so              # (its streams and events go now, not when a garbage collector gets to it)
             except Exception as ex:  # noqa: BLE001
                 print(f"bench[{rank}]: self-check of '{name}' / {sched} failed to run: {ex!r}", file=sys.stderr, flush=True)
                 ok = 0
@@ -443,6 +464,7 @@ def main():
                             print(f"bench: self-check of '{name}' / {sched}: box {f}..{l} of '{nm}' differs from the one-rank run "
                                   f"(max abs diff {float(np.abs(a.astype(np.float64) - ref).max()):.3e})", file=sys.stderr, flush=True)
                 one.end_solution()
+                del one
             same = agree_min_int(same)
             rec["schedules"][sched] = "bit-identical to one rank" if same else "DIFFERS from one rank"
             all_ok = all_ok and bool(same)

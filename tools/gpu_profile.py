@@ -45,7 +45,7 @@ def main():
     bench = [sys.executable, str(R / "bench.py"), "--no-cpu-baseline"] + argv
     run(["rocprofv3", "--kernel-trace", "--stats", "-f", "csv", "-d", str(out / "stats"), "--"] + bench, out / "stats.log")
     short = bench + ["--steps", str(pmc_steps), "--warmup", "2", "--ramp-secs", "0", "--no-probe"]
-    passes = ["FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum TCC_MISS_sum",
+    passes = ["FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum TCC_MISS_sum", "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum",
               "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE",
               "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_BUSY_CYCLES"]
     for p in passes:
@@ -93,7 +93,8 @@ def main():
             e["l2_hit_rate"] = round(d["TCC_HIT_sum"]["avg"] / max(1.0, d["TCC_HIT_sum"]["avg"] + d["TCC_MISS_sum"]["avg"]), 4)
         if "SQ_WAIT_ANY" in d and d.get("SQ_WAVE_CYCLES", {}).get("avg"):
             e["wait_any_frac"] = round(d["SQ_WAIT_ANY"]["avg"] / d["SQ_WAVE_CYCLES"]["avg"], 4)
-        for c in ("SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU"):
+        for c in ("SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_WRREQ_sum",
+                  "TCC_EA0_WRREQ_64B_sum"):
             if c in d:
                 e[c.lower()] = d[c]["avg"]
         tot_ms += s["avg_ms"]

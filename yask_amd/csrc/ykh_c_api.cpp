@@ -28,6 +28,7 @@ static Solution& S(yk_soln_h s) {
     return *s->soln;
 }
 static std::vector<idx_t> vec(Var* v, const yk_idx_t* p) {
+    if (v->dims.empty()) return {};                      // a scalar var: no indices (std::vector<idx_t>{}.data() may be null)
     if (!p) YKH_THROW("null index array");
     return std::vector<idx_t>(p, p + v->dims.size());
 }

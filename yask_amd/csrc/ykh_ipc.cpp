@@ -321,8 +321,10 @@ void ipc_free(void* p) {
     for (auto& kv : st->opened) (void)hipIpcCloseMemHandle(kv.second);
     for (int r = 0; r < (int)st->peer_mailbox.size(); r++)
         if (r != st->rank && st->peer_mailbox[r]) unmap_mailbox(st->peer_kind[r], st->peer_mailbox[r], st->peer_host[r], mb, false);
-    // the peers may still hold a mapping of my mailbox: they all pass this barrier before anybody frees
-    if (st->mesh) { long long z = 0; (void)tcp_allreduce(st->mesh, 0, &z); }
+    // NOT a collective (round 4): an env is released when its last holder goes, which a garbage-collected host (Python) decides
+    // per rank and at any time -- a barrier here deadlocked bench.py (two ranks in this destructor, two in a torch.distributed
+    // barrier; gpurun_out/r4f).  Nothing needs one: a peer's mapping of my mailbox keeps the memory behind it alive after my
+    // hipFree (IPC mappings hold a reference on the allocation), so flags it still stores land in memory nobody reads.
     if (st->mailbox) unmap_mailbox(st->kind, st->mailbox, st->mailbox_host, mb, true);
     if (!st->shm_name.empty()) (void)shm_unlink(st->shm_name.c_str());
     if (st->mesh) { for (int fd : st->mesh->fd) if (fd >= 0) ::close(fd); delete st->mesh; }

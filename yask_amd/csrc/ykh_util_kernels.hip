@@ -217,17 +217,35 @@ void launch_copy_pads(const void* src, void* dst, int elem_bytes, const idx_t al
 // What this device delivers right now to a 16-byte-per-lane streaming kernel with the stencil's read:write mix --
 // printed by bench.py next to the roofline fraction (a box in a low-power state or with slow HBM shows up here).
 typedef float f4 __attribute__((ext_vector_type(4)));
-template <int KIND>
+// Round 4: the first version kept ONE 16-byte load per lane in flight per array (load, wait, store, next)
+// and read 5.0 TB/s for a copy on a box where the stencil kernel itself moved 6.27 TB/s -- a probe slower than the kernel it is
+// meant to put into perspective.  Now every lane issues UNR independent 16-byte loads per array (one-touch: non-temporal)
+// before it touches any of them, i.e. 2048 workgroups x 256 lanes x UNR x 16 B = 128 KiB in flight per CU and array, and
+// stores non-temporally.
+template <int KIND, int UNR>
 __global__ void __launch_bounds__(256) bw_probe_k(const f4* __restrict__ a, const f4* __restrict__ b, const f4* __restrict__ c,
                                                   f4* __restrict__ d, size_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t chunk = (size_t)blockDim.x * UNR, stride = (size_t)gridDim.x * chunk;
     f4 acc = f4(0.f);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        if constexpr (KIND == 0) __builtin_nontemporal_store(a[i], &d[i]);
-        else if constexpr (KIND == 1) {
-            f4 x = a[i], y = __builtin_nontemporal_load(&b[i]), z = __builtin_nontemporal_load(&c[i]);
-            __builtin_nontemporal_store(x + y * z, &d[i]);
-        } else acc += a[i];
+    for (size_t i0 = (size_t)blockIdx.x * chunk + threadIdx.x; i0 < n; i0 += stride) {
+        f4 x[UNR], y[UNR], z[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const size_t i = i0 + (size_t)u * blockDim.x;
+            if (i < n) {
+                x[u] = __builtin_nontemporal_load(&a[i]);
+                if constexpr (KIND == 1) { y[u] = __builtin_nontemporal_load(&b[i]); z[u] = __builtin_nontemporal_load(&c[i]); }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const size_t i = i0 + (size_t)u * blockDim.x;
+            if (i < n) {
+                if constexpr (KIND == 0) __builtin_nontemporal_store(x[u], &d[i]);
+                else if constexpr (KIND == 1) __builtin_nontemporal_store(x[u] + y[u] * z[u], &d[i]);
+                else acc += x[u];
+            }
+        }
     }
     if constexpr (KIND == 2) if (acc.x == 123.456f) d[0] = acc;
 }
@@ -411,9 +429,9 @@ double probe_bandwidth(int kind, size_t bytes, int reps) {
     double best = 0;
     for (int it = 0; it < reps + 1; it++) {
         YKH_HIP(hipEventRecord(r.e0, r.st));
-        if (kind == 0) hipLaunchKernelGGL(bw_probe_k<0>, grid, block, 0, r.st, a, b, c, d, n);
-        else if (kind == 1) hipLaunchKernelGGL(bw_probe_k<1>, grid, block, 0, r.st, a, b, c, d, n);
-        else hipLaunchKernelGGL(bw_probe_k<2>, grid, block, 0, r.st, a, b, c, d, n);
+        if (kind == 0) hipLaunchKernelGGL((bw_probe_k<0, 4>), grid, block, 0, r.st, a, b, c, d, n);
+        else if (kind == 1) hipLaunchKernelGGL((bw_probe_k<1, 2>), grid, block, 0, r.st, a, b, c, d, n);
+        else hipLaunchKernelGGL((bw_probe_k<2, 4>), grid, block, 0, r.st, a, b, c, d, n);
         YKH_HIP(hipGetLastError());
         YKH_HIP(hipEventRecord(r.e1, r.st));
         YKH_HIP(hipEventSynchronize(r.e1));
