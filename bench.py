@@ -188,7 +188,7 @@ def _ref_harness(exe, n, steps, trials, threads, timeout, tuned=False):
     (50th-percentile) throughput over `trials` trials, as SURVEY.md section 8(d) asks; default (DSL) block sizes, or -- tuned --
     the block sizes its auto-tuner settles on before the trials (-pre_auto_tune, the reference's own default)."""
     cmd = [str(exe), "-g", str(n), "-trial_steps", str(steps), "-num_trials", str(trials)] + \
-          (["-pre_auto_tune"] if tuned else ["-no-pre_auto_tune", "-no-auto_tune"]) + ["-outer_threads", str(threads), "-sleep", "0"]
+          (["-pre_auto_tune", "-auto_tune_trial_secs", "0.25"] if tuned else ["-no-pre_auto_tune", "-no-auto_tune"]) + ["-outer_threads", str(threads), "-sleep", "0"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd="/tmp")
     res = {}
     for line in out.stdout.splitlines():
@@ -229,7 +229,7 @@ def cpu_baseline():
                     tr = _ref_harness(exe, n, 50, 2, cores, 300, tuned=True)
                     if "best" in tr:
                         tuned = {"best": round(tr["best"], 4), "mid": round(tr.get("mid", tr["best"]), 4), "secs_incl_tuning": round(time.time() - t1, 1),
-                                 "what": f"-pre_auto_tune, 2 trials x 50 steps, {n}^3"}
+                                 "what": f"-pre_auto_tune -auto_tune_trial_secs 0.25 (the tuner's default of 0.5 s per candidate took 150 s at this size), 2 trials x 50 steps, {n}^3"}
                 except Exception as e:  # noqa: BLE001
                     tuned = {"error": repr(e)[:200]}
             if "best" in r:
@@ -621,6 +621,7 @@ def main():
         ramp_steps += more
     soln.get_stats()
     # ---- timed region: EXACTLY K steps between two barriers
+    tc0 = env.get_transport_counters() if world > 1 else {}
     barrier()
     t0 = time.perf_counter()
     soln.run_solution(t, t + args.steps - 1)      # returns after the streams have drained
@@ -628,6 +629,7 @@ def main():
     elapsed = time.perf_counter() - t0
     t += args.steps
     elapsed = agree_max(elapsed)
+    tc1 = env.get_transport_counters() if world > 1 else {}
     step_ms = soln.get_step_times()
     st = soln.get_stats()
     if rank == 0:
@@ -663,7 +665,7 @@ def main():
         try:
             probe = {"copy_1r1w_gbs": round(env.probe_bandwidth(0, 1 << 30, 3), 1), "stencil_mix_3r1w_gbs": round(env.probe_bandwidth(1, 1 << 30, 3), 1),
                      "read_only_gbs": round(env.probe_bandwidth(2, 1 << 30, 3), 1),
-                     "what": "16-byte-per-lane streaming kernels over 1 GiB per array, best of 3, this process, after the timed region"}
+                     "what": "streaming kernels, 4 independent 16-byte non-temporal loads per lane and array in flight, 1 GiB per array, best of 3, this process, after the timed region"}
         except Exception as e:  # noqa: BLE001
             probe = {"error": repr(e)}
 
@@ -687,8 +689,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": round(kern_ms, 4), "kernel_ms_source": kern_src, "algorithmic_bytes_per_launch": BYTES_PER_POINT * pts_per_gpu,
-                         "frac_of_this_box_stencil_mix": (round(achieved / probe["stencil_mix_3r1w_gbs"], 4)
-                                                          if probe and probe.get("stencil_mix_3r1w_gbs") else None)},
+                         # (algorithmic bytes of the stencil against what a plain copy kernel moves on this box now; the stencil's
+                         #  own fabric traffic is `traffic` / kernel time)
+                         "frac_of_this_box_copy": (round(achieved / probe["copy_1r1w_gbs"], 4) if probe and probe.get("copy_1r1w_gbs") else None)},
             "gpoints_per_s_per_gpu": round(value / world, 3),
             "per_gpu_roofline_frac_whole_step": round(value / world * BYTES_PER_POINT / HBM_PEAK_GBS, 4),
             "step_ms": ({"min": round(min(step_ms), 4), "median": round(statistics.median(step_ms), 4), "max": round(max(step_ms), 4),
@@ -707,7 +710,13 @@ def main():
                                            "interior": round(st.get_interior_secs() / args.steps * 1e3, 4),
                                            "exposed_wait": round(st.get_halo_wait_secs() / args.steps * 1e3, 4)},
                            "comm_hidden_fraction": (round(max(0.0, 1.0 - st.get_halo_wait_secs() / comm), 4) if comm > 0 else None),
-                           "source": "HIP events on the compute and communication streams of rank 0 (yk_stats)"}
+                           "source": "HIP events on the compute and communication streams of rank 0 (yk_stats)",
+                           # the IPC transport counts its own control plane: registrations over the TCP mesh (0 in steady state: the host
+                           # is out of the exchange loop), flag kernels + copies enqueued per step, where its flag words live
+                           "ipc_control_plane_rank0": ({"control_msgs_in_timed_region": tc1["ctl_msgs"] - tc0["ctl_msgs"],
+                                                       "device_ops_per_step": round((tc1["dev_ops"] - tc0["dev_ops"]) / max(1, args.steps), 2),
+                                                       "mailbox_memory": ["uncached device", "fine-grained device", "plain device", "pinned host"][tc1["mailbox_kind"]]}
+                                                      if tc1.get("ctl_msgs") is not None and tc0.get("ctl_msgs") is not None else None)}
         if world == 1 and not args.no_cpu_baseline and args.workload == "iso3dfd":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -223,11 +223,10 @@ def test_ssg_512_one_rank_matches_reference_lattice_and_oracle_and_eight_ranks_m
     # (c) BASELINE config 5 names "multi-var halos + temporal blocking": the same eight blocks with wave-front tiling across the
     # ranks (-Mbt 2: groups of two steps = four phases on shrinking extended boxes, ONE exchange per group with all 26
     # neighbours; the reference: setup.cpp:717-805, context.cpp:286-346) -- same kernels, so bit for bit again
-    plain_msgs = {rank: info["msgs"] for rank, _, _, _, _, info in parts}
     parts = _run_ranks(8, "ssg", g, (2, 2, 2), steps, "-Mbt 2", "ipc", stride)
     for rank, f, l, _, _, info in parts:
         print(f"-Mbt 2 rank {rank} box {f}..{l}: {info}")
-        assert info["msgs"] == 7 * ((steps + 1) // 2 + 1) and info["msgs"] < plain_msgs[rank]      # 7 neighbours, once per group (+ the initial exchange)
+        assert info["msgs"] == 7 * ((steps + 1) // 2 + 1)      # all 7 neighbours of a corner rank, once per group (+ the initial exchange)
     _check_against_one_rank_and_reference(parts, one, "ssg", g, steps, stride, G / "c5_ssg_512_s3_lattice.npz", False)
     for k in list(_ONE):
         _ONE.pop(k).end_solution()

@@ -250,3 +250,7 @@ def test_bench_on_real_devices_with_its_self_check(n):
     assert sc["transports"] and all(v["ok"] for v in sc["transports"].values()), sc
     assert j["config"]["halo_transport"] in sc["transports"]
     assert sc["devices"] == (1 if DRYRUN else n)
+    if j["config"]["halo_transport"] == "ipc":       # the host is out of the exchange loop: no registration travels during the timed steps
+        cp = j["halo"]["ipc_control_plane_rank0"]
+        assert cp["control_msgs_in_timed_region"] == 0 and cp["device_ops_per_step"] > 0
+        assert DRYRUN or cp["mailbox_memory"] != "plain device"

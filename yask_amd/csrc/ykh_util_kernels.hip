@@ -430,7 +430,7 @@ double probe_bandwidth(int kind, size_t bytes, int reps) {
     for (int it = 0; it < reps + 1; it++) {
         YKH_HIP(hipEventRecord(r.e0, r.st));
         if (kind == 0) hipLaunchKernelGGL((bw_probe_k<0, 4>), grid, block, 0, r.st, a, b, c, d, n);
-        else if (kind == 1) hipLaunchKernelGGL((bw_probe_k<1, 2>), grid, block, 0, r.st, a, b, c, d, n);
+        else if (kind == 1) hipLaunchKernelGGL((bw_probe_k<1, 4>), grid, block, 0, r.st, a, b, c, d, n);
         else hipLaunchKernelGGL((bw_probe_k<2, 4>), grid, block, 0, r.st, a, b, c, d, n);
         YKH_HIP(hipGetLastError());
         YKH_HIP(hipEventRecord(r.e1, r.st));
