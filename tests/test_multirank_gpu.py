@@ -172,7 +172,7 @@ def test_bench_two_ranks_on_one_gpu(gpu):
     assert j["halo"]["bytes_sent_per_step_rank0"] > 0 and j["step_ms"]["n"] == 4
     # the step's launch schedule was picked by timing every candidate during warm-up (max over ranks), and is reported
     tr = j["config"]["schedule_trials_ms_per_step"]
-    assert set(tr) == {"planned", "planned35", "planned_inlinepack", "halves", "slabs", "serial"} and all(v > 0 for v in tr.values())
+    assert set(tr) == {"planned", "halves", "serial"} and all(v > 0 for v in tr.values())
     assert j["config"]["schedule"] == min(tr, key=tr.get) and j["config"]["overlap_comms"] == (j["config"]["schedule"] != "serial")
     # the default mode cuts ONE global grid over the ranks (strong scaling, north_star's "1024^3 at 1, 2, 4, 8")
     cmd[cmd.index("--config") + 1] = "c2"

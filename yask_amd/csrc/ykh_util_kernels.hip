@@ -365,6 +365,9 @@ struct WaitWords { const unsigned* p[32]; unsigned v[32]; int n; };
 __global__ void __launch_bounds__(64) wait_words_kernel(WaitWords w, unsigned* err, unsigned spins) {
     const int i = threadIdx.x;
     bool ok = i >= w.n;
+    // a waiter before this one has already given up (the error word stays raised until the host has seen it): the exchange is lost,
+    // do not make the stream sit through one time-out per remaining wait of the run -- a failing run costs ONE time-out
+    if (err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
     for (unsigned k = 0; k < spins; k++) {
         if (!ok) ok = (int)(__hip_atomic_load(w.p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - w.v[i]) >= 0;
         if (__all(ok)) break;
