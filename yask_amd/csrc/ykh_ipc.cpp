@@ -246,7 +246,9 @@ int ipc_start(void* user, int n, const ykh::HaloMsg* m, void* stream_) {
             continue;
         }
         if (!sc[i]) continue;
-        if (hipMemcpyAsync(sc[i]->dst, m[i].send_buf, m[i].send_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) {
+        // (hipMemcpyDefault: the destination is another process's allocation, possibly on another device -- the runtime picks the
+        //  path, SDMA over xGMI or a blit, from the pointers)
+        if (hipMemcpyAsync(sc[i]->dst, m[i].send_buf, m[i].send_bytes, hipMemcpyDefault, stream) != hipSuccess) {
             fprintf(stderr, "yask ipc transport: copy into rank %d's buffer failed: %s\n", m[i].peer, hipGetErrorString(hipGetLastError()));
             return 1;
         }
