@@ -42,9 +42,24 @@ bool send_all(int fd, const void* p, size_t n) {
     }
     return true;
 }
+// A control message that never comes must end as an error, not as a hung job (a rank that died keeps its socket open when its
+// process is only stopped; ranks that post different exchanges wait for each other for ever): every read gives up after
+// YASK_HIP_MESH_TIMEOUT_S seconds (default 900 -- ranks legitimately wait here while another one validates or tunes).
+static int mesh_timeout_ms() {
+    static const int ms = [] {
+        const char* t = getenv("YASK_HIP_MESH_TIMEOUT_S");
+        const double v = t ? atof(t) : 0;
+        return (int)std::min(2.0e9, (v > 0 ? v : 900.0) * 1000.0);
+    }();
+    return ms;
+}
 bool recv_all(int fd, void* p, size_t n) {
     char* c = (char*)p;
     while (n) {
+        pollfd pf{}; pf.fd = fd; pf.events = POLLIN;
+        const int pr = ::poll(&pf, 1, mesh_timeout_ms());
+        if (pr < 0) { if (errno == EINTR) continue; return false; }
+        if (pr == 0) { fprintf(stderr, "yask control mesh: nothing arrived in %d s (a peer is stuck, dead, or posts another exchange)\n", mesh_timeout_ms() / 1000); return false; }
         ssize_t k = ::recv(fd, c, n, 0);
         if (k < 0) { if (errno == EINTR) continue; return false; }
         if (k == 0) return false;
