@@ -12,7 +12,8 @@ import re
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-LIB_DIR = _PKG / "lib"
+# YASK_HIP_LIB_DIR: another directory of kernel libraries (e.g. a `make YKH_PROFILING=1 LIBDIR=...` build with the sweep shapes)
+LIB_DIR = Path(os.environ["YASK_HIP_LIB_DIR"]) if os.environ.get("YASK_HIP_LIB_DIR") else _PKG / "lib"
 HEADER = _PKG.parent / "include" / "yask_hip_c_api.h"
 
 idx_t = C.c_int64
