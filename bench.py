@@ -589,17 +589,35 @@ def main():
             # (round 4: three candidates -- the exchange after the launch, and the two overlapping schedules; planned35 /
             #  planned_inlinepack / slabs differ from these by less than the placement lottery on the one-GPU instruments and stay
             #  selectable with --schedule)
+            def trial(fn):
+                """run fn on this rank; True only if it worked on EVERY rank (the same collectives are issued either way)"""
+                ok = 1
+                try:
+                    fn()
+                    torch.cuda.synchronize()
+                except Exception as ex:  # noqa: BLE001
+                    print(f"bench[{rank}]: schedule trial failed: {ex!r}", file=sys.stderr, flush=True)
+                    ok = 0
+                return agree_min_int(ok) == 1
+
             for name, opt in ((k, SCHEDULES[k]) for k in AUTO_SCHEDULES):
                 assert soln.apply_command_line_options(opt) == ""
-                soln.run_solution(t, t + 1)                      # untimed: first use of this schedule's launches / messages
+                t0_ = t
+                good = trial(lambda: soln.run_solution(t0_, t0_ + 1))   # untimed: first use of this schedule's launches / messages
                 t += 2
-                barrier()
-                w0 = time.perf_counter()
-                soln.run_solution(t, t + 7)
-                barrier()
-                schedule_ms[name] = round(agree_max(time.perf_counter() - w0) / 8 * 1e3, 4)
-                t += 8
-            schedule = min(schedule_ms, key=schedule_ms.get)     # (the same on every rank: the timings are max-reduced)
+                if good:
+                    barrier()
+                    w0 = time.perf_counter()
+                    t1_ = t
+                    good = trial(lambda: soln.run_solution(t1_, t1_ + 7))
+                    dt = agree_max(time.perf_counter() - w0)
+                    t += 8
+                # (a schedule that fails on some rank -- a waiter's time-out on a link that does not deliver -- is out, not the job)
+                schedule_ms[name] = round(dt / 8 * 1e3, 4) if good else None
+            usable_s = {k: v for k, v in schedule_ms.items() if v is not None}
+            if not usable_s:
+                raise SystemExit(f"bench.py: no step schedule ran on every rank: {schedule_ms}")
+            schedule = min(usable_s, key=usable_s.get)           # (the same on every rank: the timings are max-reduced)
         assert soln.apply_command_line_options(SCHEDULES[schedule]) == ""
         soln.get_stats()
 
