@@ -5,6 +5,9 @@ namespace ykh {
 using namespace ykh_gen_3axis;
 void s3axis_variants_k2(PartImpl& p) {
     p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_MOVE, 1, 2, 4>());
+#ifdef YKH_PROFILING      // write-through output stores: measured 1-12 % slower, profiles/r4_wt
+    p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_MOVE, 1 | 128, 2, 4>());
+#endif
 #ifdef YKH_PROFILING      // sweep shapes: measured, documented, never selected -- built with `make YKH_PROFILING=1` only
     p.variants.push_back(starlin_variant<part_1, 2, 64, 16, 1, ROT_MOVE, 1, 4, 4>());
     p.variants.push_back(starlin_variant<part_1, 2, 32, 16, 2, ROT_UNROLL, 1, 2, 4>());

@@ -22,6 +22,9 @@ void s3axis_variants_k4(PartImpl& p) {
     p.variants.push_back(starlin_variant<part_1, 2, 64, 16, 1, ROT_TRIP2, 25, 4, 4>());   // + operands two planes ahead
 #endif
     p.variants.push_back(starlin_variant<part_1, 2, 32, 16, 2, ROT_UNROLL, 1 | 64, 2, 4>());   // the default shape + cheap tail planes (_tl)
+#ifdef YKH_PROFILING      // write-through output stores: measured 1-12 % slower, profiles/r4_wt
+    p.variants.push_back(starlin_variant<part_1, 2, 32, 16, 2, ROT_UNROLL, 1 | 64 | 128, 2, 4>());
+#endif
 #ifdef YKH_PROFILING      // sweep shapes: measured, documented, never selected -- built with `make YKH_PROFILING=1` only
     p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_MOVE, 1 | 64, 2, 4>());      // the large-grid shape + cheap tail planes
 #endif

@@ -18,6 +18,9 @@ void iso3dfd_variants_k4(PartImpl& p) {
 #endif
     p.variants.push_back(starlin_variant_planned<part_1, 4, 32, 16, 2, ROT_TRIP2, 9 | 64, 2, 2>());      // 256 VGPRs, no scratch
     p.variants.push_back(starlin_variant_planned<part_1, 4, 32, 16, 2, ROT_TRIP, 9 | 64, 2, 2>());
+#ifdef YKH_PROFILING      // write-through output stores: measured 1-12 % slower, profiles/r4_wt
+    p.variants.push_back(starlin_variant_planned<part_1, 4, 32, 16, 2, ROT_TRIP2, 9 | 64 | 128, 2, 2>());
+#endif
 #ifdef YKH_PROFILING      // sweep shapes: measured, documented, never selected -- built with `make YKH_PROFILING=1` only
     p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 9 | 64, 2, 2>());   // + 4-plane trips
     p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_MOVE, 29, 2, 2, 0>());   // + both, halos at the end

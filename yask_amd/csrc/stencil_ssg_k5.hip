@@ -12,6 +12,9 @@ void ssg_variants_k5(PartImpl& p) {
 #endif
     p.variants.push_back(march_variant_planned<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 16>());        // exact arithmetic, trips of 2
     p.variants.push_back(march_variant_planned<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8 | 16>());
+#ifdef YKH_PROFILING      // write-through output stores: measured 1-12 % slower, profiles/r4_wt
+    p.variants.push_back(march_variant<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8 | 16 | 256>());
+#endif
 #ifdef YKH_PROFILING      // sweep shapes: measured, documented, never selected -- built with `make YKH_PROFILING=1` only
     p.variants.push_back(march_variant<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8 | 32>());    // trips of 4: 256 VGPRs, no spill
     p.variants.push_back(march_variant<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8 | 16 | 128>());   // + late refill of the centre-only operands

@@ -8,6 +8,9 @@ void ssg_variants_k6(PartImpl& p) {
     p.variants.push_back(march_variant<part_2, 4, 32, 16, 2, 1, false, 1, 3 | 4>());             // (spills 2 registers)
 #endif
     p.variants.push_back(march_variant_planned<part_2, 4, 32, 16, 2, 1, false, 1, 3 | 8>());             // 5 divisions per point: ~200 -> ~30 instructions
+#ifdef YKH_PROFILING      // write-through output stores: measured 1-12 % slower, profiles/r4_wt
+    p.variants.push_back(march_variant<part_2, 4, 32, 16, 2, 1, false, 1, 3 | 8 | 256>());
+#endif
 #ifdef YKH_PROFILING      // sweep shapes: measured, documented, never selected -- built with `make YKH_PROFILING=1` only
     p.variants.push_back(march_variant<part_2, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8>());         // (spills 2 registers)
     p.variants.push_back(march_variant<part_2, 4, 32, 16, 2, 1, false, 1, 1 | 4 | 8>());         // without the halo rings: fits

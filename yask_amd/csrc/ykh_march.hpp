@@ -471,7 +471,10 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
                 static_for<P::n_writes>([&](auto wc) {
                     constexpr int g = P::writes[decltype(wc)::value];
                     auto ob = sbase((T*)a.ptr[g] + xo);
-                    if (whole) { if constexpr (NTS) stv_b_nt<V>(ob, ooff[j], out[g]); else stv_b<V>(ob, ooff[j], out[g]); }
+                    if (whole) {
+                        if constexpr ((FL & 256) != 0 && sizeof(V) == 16) stv_b_wt<V>(ob, ooff[j], out[g]);      // _wt: write-through, ykh_starlin.hpp
+                        else if constexpr (NTS) stv_b_nt<V>(ob, ooff[j], out[g]); else stv_b<V>(ob, ooff[j], out[g]);
+                    }
                     else
                         static_for<VZ>([&](auto ec) {
                             constexpr int e = decltype(ec)::value;

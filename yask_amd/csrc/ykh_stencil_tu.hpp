@@ -96,13 +96,13 @@ void launch_march(const PartArgs& a, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL((march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT, DESC>), grid, dim3(C::NT), C::lds_bytes, s, a);
 }
 // Generic marching kernel (ykh_march.hpp). Name: march_v<VZ>_z<tile z>_y<tile y>[_r<rows>][_pin][_pd<planes ahead>][_nt][_hr]_w<min waves/SIMD>
-// (NT: flag bits, 1 = non-temporal one-touch streams, 2 = halo rings, 4 = packed subtractions (_ps), 8 = reciprocal divisions (_fd), 16 / 32 / 64 = queue renaming in trips of 2 / 4 / 8 planes, 128 = late refill of the once operands (_lo))
+// (NT: flag bits, 1 = non-temporal one-touch streams, 2 = halo rings, 4 = packed subtractions (_ps), 8 = reciprocal divisions (_fd), 16 / 32 / 64 = queue renaming in trips of 2 / 4 / 8 planes, 128 = late refill of the once operands (_lo), 256 = write-through output stores (_wt, ykh_starlin.hpp stv_b_wt))
 template <class P, int VZ, int TZL, int TYL, int MINW, int RY = 1, bool PIN = false, int PD = 1, int NT = 0>
 KernelVariant march_variant() {
     typedef MarchCfg<P, VZ, TZL, TYL, RY, (NT & 2) != 0> C;
     static_assert(C::lds_bytes <= 160 * 1024, "march tile does not fit the 160 KiB LDS");
     static const std::string name = "march_v" + std::to_string(VZ) + "_z" + std::to_string(C::TZ) + "_y" +
-                                    std::to_string(C::TY) + (RY > 1 ? "_r" + std::to_string(RY) : "") + (PIN ? "_pin" : "") + (PD > 1 ? "_pd" + std::to_string(PD) : "") + ((NT & 1) ? "_nt" : "") + ((NT & 2) ? "_hr" : "") + ((NT & 4) ? "_ps" : "") + ((NT & 8) ? "_fd" : "") + ((NT & 64) ? "_t8" : ((NT & 32) ? "_t4" : ((NT & 16) ? "_t2" : ""))) + ((NT & 128) ? "_lo" : "") + "_w" + std::to_string(MINW);
+                                    std::to_string(C::TY) + (RY > 1 ? "_r" + std::to_string(RY) : "") + (PIN ? "_pin" : "") + (PD > 1 ? "_pd" + std::to_string(PD) : "") + ((NT & 1) ? "_nt" : "") + ((NT & 2) ? "_hr" : "") + ((NT & 4) ? "_ps" : "") + ((NT & 8) ? "_fd" : "") + ((NT & 64) ? "_t8" : ((NT & 32) ? "_t4" : ((NT & 16) ? "_t2" : ""))) + ((NT & 128) ? "_lo" : "") + ((NT & 256) ? "_wt" : "") + "_w" + std::to_string(MINW);
     KernelVariant kv{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_march<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT>};
     kv.vz = VZ;
     kv.func = reinterpret_cast<const void*>(&march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT>);
@@ -127,7 +127,7 @@ KernelVariant starlin_variant() {
     static const std::string name = std::string(ABL ? "abl" + std::to_string(ABL) + "_" : "") + "starlin_v" + std::to_string(VZ) +
                                     "_z" + std::to_string(C::TZ) + "_y" + std::to_string(C::TY) + "_r" +
                                     std::to_string(RY) + (ROT == ROT_UNROLL ? "_u" : (ROT == ROT_TRIP ? "_t" : (ROT == ROT_TRIP2 ? "_t2" : "_m"))) + ((NTH & 1) ? "_nt" : "") +
-                                    (((NTH >> 1) & 3) ? "_hl" + std::to_string((NTH >> 1) & 3) : "") + ((NTH & 32) ? "_pd3" : ((NTH & 8) ? "_pd2" : "")) + ((NTH & 16) ? "_cd2" : "") + ((NTH & 64) ? "_tl" : "") + "_w" +
+                                    (((NTH >> 1) & 3) ? "_hl" + std::to_string((NTH >> 1) & 3) : "") + ((NTH & 32) ? "_pd3" : ((NTH & 8) ? "_pd2" : "")) + ((NTH & 16) ? "_cd2" : "") + ((NTH & 64) ? "_tl" : "") + ((NTH & 128) ? "_wt" : "") + "_w" +
                                     std::to_string(MINW) + "_c" + std::to_string(CH);
     KernelVariant kv{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_starlin<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL>};
     kv.vz = VZ;
