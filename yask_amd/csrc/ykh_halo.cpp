@@ -78,7 +78,7 @@ void Solution::alloc_halo_buffers() {
                 }
             }
         // in-place transfer? (decided from geometry only, so both ends of a link agree)
-        x->direct = direct_halo && !wf_multi() && ndd == 3 && nb.ofs[0] != 0 && nb.ofs[1] == 0 && nb.ofs[2] == 0 &&
+        x->direct = direct_halo && env->direct_halo_ok && !wf_multi() && ndd == 3 && nb.ofs[0] != 0 && nb.ofs[1] == 0 && nb.ofs[2] == 0 &&
                     x->send.size() == x->recv.size() && !x->send.empty();
         for (auto* lst : {&x->send, &x->recv})
             for (const Slab& sl : *lst) {

@@ -92,6 +92,7 @@ struct IpcState {
     std::map<long long, SendChan> send_chan;     // (peer, tag, key) -> where my message goes
     std::map<long long, RecvChan> recv_chan;     // (peer, the SENDER's tag, key) -> which channel I gave it
     std::vector<int> next_chan;                  // per sender: channels handed out so far
+    int verbose = 0;                             // YASK_HIP_IPC_VERBOSE=2: every control-plane step on stderr
     bool stale = false;                          // buffers behind registrations were freed / moved since the last collective reset
     double timeout_s = 20.0;
     std::vector<const unsigned*> wait_ptr;       // per message of the exchange in flight: its `ready` word ...
@@ -143,7 +144,9 @@ int ipc_begin(void* user) {
     IpcState* st = static_cast<IpcState*>(user);
     st->begins++;
     long long v = st->stale ? 1 : 0;
+    if (st->verbose > 1) fprintf(stderr, "ipc[%d]: begin #%lld (stale %lld)\n", st->rank, st->begins, v);
     if (tcp_allreduce(st->mesh, 2, &v) != 0) return 1;
+    if (st->verbose > 1) fprintf(stderr, "ipc[%d]: begin agreed: %s\n", st->rank, v ? "reset" : "keep");
     if (!v) return 0;
     st->resets++;
     if (hipDeviceSynchronize() != hipSuccess) return 1;       // my copies and flag stores of earlier exchanges have landed
@@ -174,6 +177,7 @@ int ipc_start(void* user, int n, const ykh::HaloMsg* m, void* stream_) {
     // ---- host side, FIRST USE of a channel only: tell the sender where its data goes (all sends first, then the receives:
     // 96-byte messages, far below a socket buffer)
     std::vector<RecvChan*> rc(n, nullptr);
+    std::map<int, bool> sent_to;                              // peers that got a registration from me in THIS exchange
     for (int i = 0; i < n; i++) {
         if (m[i].peer == st->rank || !m[i].recv_bytes) continue;
         const long long k = chan_key(m[i].peer, 26 - m[i].tag, m[i].key);       // the channel is named by the tag its SENDER uses
@@ -185,7 +189,9 @@ int ipc_start(void* user, int n, const ykh::HaloMsg* m, void* stream_) {
             if (!export_buf(st, m[i].recv_buf, &rg.handle, &rg.offset, &rg.room)) { fprintf(stderr, "yask ipc transport: cannot export a receive buffer\n"); return 1; }
             if (rg.room < m[i].recv_bytes) { fprintf(stderr, "yask ipc transport: a receive buffer is shorter than its message\n"); return 1; }
             if (!send_all(st->mesh->fd[m[i].peer], &rg, sizeof(rg))) return 1;
+            if (st->verbose > 1) fprintf(stderr, "ipc[%d]: registered (sender's tag %d, key %d) as channel %d with rank %d, %zu bytes\n", st->rank, rg.tag, rg.key, rg.chan, m[i].peer, m[i].recv_bytes);
             st->ctl_msgs++; st->ctl_bytes += (long long)sizeof(rg);
+            sent_to[m[i].peer] = true;
             st->next_chan[m[i].peer]++;
             it = st->recv_chan.emplace(k, RecvChan{rg.chan, m[i].recv_buf, 0u}).first;
         } else if (it->second.buf != m[i].recv_buf) {
@@ -195,21 +201,59 @@ int ipc_start(void* user, int n, const ykh::HaloMsg* m, void* stream_) {
         }
         rc[i] = &it->second;
     }
+    // The other direction: addresses of the peers' buffers for MY messages.  Mapping a peer's allocation (hipIpcOpenMemHandle) is
+    // ORDERED between the two ends of a link: when both map each other's buffers in the same exchange, the lower rank maps first
+    // and then sends a token, the higher rank waits for it.  Four bench.py ranks, released from a barrier at the same instant,
+    // each sat in hipIpcOpenMemHandle on its x neighbour's 2.6 GB var while that neighbour sat in the same call on theirs --
+    // for good (gpurun_out/r4t: 0 <-> 1, 2 <-> 3); ranks that arrive a few microseconds apart never showed it.  A rank only ever
+    // waits for LOWER ranks, so the waits cannot form a cycle; all of this happens at the first use of a channel only.
     std::vector<SendChan*> sc(n, nullptr);
+    std::map<int, std::vector<Registration>> pending;      // peer -> registrations read, not yet mapped
+    std::map<int, bool> token_from;
+    auto read_record = [&](int peer) -> bool {                // one record from a peer: a registration (kept) or a token
+        Registration rg{};
+        if (!recv_all(st->mesh->fd[peer], &rg, sizeof(rg))) { fprintf(stderr, "yask ipc transport: rank %d lost the control link to rank %d\n", st->rank, peer); return false; }
+        if (rg.tag == -1) { token_from[peer] = true; return true; }
+        if (rg.tag < 0 || rg.tag >= TAGS || rg.chan < 0 || rg.chan >= CHANS) { fprintf(stderr, "yask ipc transport: malformed registration from rank %d\n", peer); return false; }
+        pending[peer].push_back(rg);
+        return true;
+    };
     for (int i = 0; i < n; i++) {
         if (m[i].peer == st->rank || !m[i].send_bytes) continue;
-        const long long k = chan_key(m[i].peer, m[i].tag, m[i].key);
-        auto it = st->send_chan.find(k);
-        while (it == st->send_chan.end()) {
-            // the receiver posts the same exchange: its registration for this channel is on its way (others of the link may come first)
-            Registration rg{};
-            if (!recv_all(st->mesh->fd[m[i].peer], &rg, sizeof(rg))) { fprintf(stderr, "yask ipc transport: rank %d lost the control link to rank %d\n", st->rank, m[i].peer); return 1; }
-            if (rg.tag < 0 || rg.tag >= TAGS || rg.chan < 0 || rg.chan >= CHANS) { fprintf(stderr, "yask ipc transport: malformed registration from rank %d\n", m[i].peer); return 1; }
-            void* base = import_buf(st, m[i].peer, rg.handle);
-            if (!base) return 1;
-            st->send_chan[chan_key(m[i].peer, rg.tag, rg.key)] = SendChan{rg.chan, (char*)base + rg.offset, rg.room, 0u};
-            it = st->send_chan.find(k);
+        const int peer = m[i].peer;
+        if (st->send_chan.count(chan_key(peer, m[i].tag, m[i].key))) continue;
+        // the receiver posts the same exchange: its registration for this channel is on its way (others of the link may come first)
+        auto have = [&]() { for (const Registration& r : pending[peer]) if (r.tag == m[i].tag && r.key == m[i].key) return true; return false; };
+        while (!have()) {
+            if (st->verbose > 1) fprintf(stderr, "ipc[%d]: waiting for rank %d's registration of (tag %d, key %d), %zu bytes to send\n", st->rank, peer, m[i].tag, m[i].key, m[i].send_bytes);
+            if (!read_record(peer)) return 1;
         }
+    }
+    for (auto& kv : pending) {                                 // (std::map: peers in increasing rank order)
+        const int peer = kv.first;
+        const bool mutual = sent_to.count(peer) != 0;          // the peer maps MY buffers in this exchange as well
+        if (mutual && peer < st->rank)
+            while (!token_from[peer]) {
+                if (st->verbose > 1) fprintf(stderr, "ipc[%d]: waiting for rank %d to finish mapping my buffers\n", st->rank, peer);
+                if (!read_record(peer)) return 1;
+            }
+        for (const Registration& rg : kv.second) {
+            if (st->verbose > 1) fprintf(stderr, "ipc[%d]: mapping rank %d's buffer of (tag %d, key %d)\n", st->rank, peer, rg.tag, rg.key);
+            void* base = import_buf(st, peer, rg.handle);
+            if (!base) return 1;
+            st->send_chan[chan_key(peer, rg.tag, rg.key)] = SendChan{rg.chan, (char*)base + rg.offset, rg.room, 0u};
+        }
+        if (mutual && peer > st->rank) {
+            Registration tok{};
+            tok.tag = -1;
+            if (!send_all(st->mesh->fd[peer], &tok, sizeof(tok))) return 1;
+            st->ctl_msgs++; st->ctl_bytes += (long long)sizeof(tok);
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        if (m[i].peer == st->rank || !m[i].send_bytes) continue;
+        auto it = st->send_chan.find(chan_key(m[i].peer, m[i].tag, m[i].key));
+        if (it == st->send_chan.end()) { fprintf(stderr, "yask ipc transport: rank %d has no address for (peer %d, tag %d, key %d)\n", st->rank, m[i].peer, m[i].tag, m[i].key); return 1; }
         if (it->second.room < m[i].send_bytes) {
             fprintf(stderr, "yask ipc transport: rank %d: message of %zu bytes for (peer %d, tag %d, key %d) exceeds the %llu bytes registered\n",
                     st->rank, m[i].send_bytes, m[i].peer, m[i].tag, m[i].key, it->second.room);
@@ -217,6 +261,7 @@ int ipc_start(void* user, int n, const ykh::HaloMsg* m, void* stream_) {
         }
         sc[i] = &it->second;
     }
+    if (st->verbose > 1) fprintf(stderr, "ipc[%d]: exchange of %d messages: addresses known, enqueueing\n", st->rank, n);
     // ---- device side, on the comm stream
     std::vector<unsigned*> sp;
     std::vector<const unsigned*> wp;
@@ -363,6 +408,7 @@ int yk_env_init_ipc(yk_env_h e, int rank, int nranks, const char* addr, int base
         auto* st = new IpcState;
         st->rank = rank; st->nranks = nranks;
         if (const char* t = getenv("YASK_HIP_WAIT_TIMEOUT_S")) { const double v = atof(t); if (v > 0) st->timeout_s = v; }
+        if (const char* t = getenv("YASK_HIP_IPC_VERBOSE")) st->verbose = atoi(t);
         st->mesh = tcp_connect_mesh(rank, nranks, addr && *addr ? addr : "127.0.0.1", base_port);
         if (!st->mesh) { fprintf(stderr, "yask ipc transport: rank %d could not connect the control mesh\n", rank); delete st; return 1; }
         st->next_chan.assign(nranks, 0);
@@ -468,6 +514,8 @@ int yk_env_init_ipc(yk_env_h e, int rank, int nranks, const char* addr, int base
         e->env->exch_begin = ipc_begin;
         e->env->exch_check = ipc_check;
         e->env->exch_counters = ipc_counters;
+        // (no peer maps var storage unless asked to: YASK_HIP_IPC_DIRECT=1 brings the in-place x faces back, see Env::direct_halo_ok)
+        { const char* d = getenv("YASK_HIP_IPC_DIRECT"); e->env->direct_halo_ok = d && atoi(d) != 0; }
         e->env->allreduce = ipc_allreduce;
         e->env->user = st;
         e->env->user_free = ipc_free;

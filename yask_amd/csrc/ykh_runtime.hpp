@@ -150,12 +150,18 @@ public:
     void (*user_free)(void*) = nullptr;     // releases `user` (built-in transports own their state; host callbacks do not)
     bool trace = false;
     int solutions_made = 0;                 // ordinal of the next Solution of this env (HaloMsg::key)
+    // false: the installed transport reaches a peer's receive buffer by MAPPING the allocation it lies in (ykh_ipc.cpp) -- x faces then
+    // travel through the packed buffers like y / z faces instead of straight into the var's planes: a peer never maps var storage
+    // (round 4: four bench.py ranks at the headline size hung in hipIpcOpenMemHandle on each other's 2.6 GB vars, gpurun_out/r4t;
+    // with packed x faces the same job runs, r4v; the two extra copies of contiguous planes cost < 1 % of a step)
+    bool direct_halo_ok = true;
     // a new transport is about to be installed: the old one's state goes, and so does every hook it had set
     void drop_transport() {
         if (user && user_free) user_free(user);
         user = nullptr; user_free = nullptr;
         exch_start = exch_wait = nullptr; allreduce = nullptr;
         exch_reset = nullptr; exch_begin = nullptr; exch_check = nullptr; exch_counters = nullptr;
+        direct_halo_ok = true;
     }
     Env();
     ~Env() { if (user && user_free) user_free(user); }
