@@ -494,9 +494,29 @@ def main():
     # timed steps on the default schedule, the times are max-reduced over the ranks, the faster one runs the benchmark and both
     # numbers are reported.  A candidate that cannot be set up on every rank, fails the self-check or its trial, is skipped (and
     # reported).  Every rank issues the same sequence of collectives whether or not a phase failed locally.
+    def ipc_preflight(grid_):
+        """the IPC transport in a CHILD process first (yask_amd/ipc_preflight.py): a transport whose set-up or first exchanges hang on
+        this node hangs a child that can be killed, not this job.  True only if every rank's child came back with exit code 0."""
+        child_env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 300), PYTHONPATH=str(ROOT))
+        child_env.pop("YASK_BENCH_STACK_DUMP_S", None)
+        ok = 0
+        try:
+            r = subprocess.run([sys.executable, "-m", "yask_amd.ipc_preflight", stencil] + [str(g) for g in grid_], cwd=str(ROOT), env=child_env,
+                               capture_output=True, text=True, timeout=float(os.environ.get("YASK_BENCH_IPC_PREFLIGHT_S", "60")))
+            ok = 1 if r.returncode == 0 else 0
+            if not ok:
+                print(f"bench[{rank}]: ipc preflight failed (exit {r.returncode}): {r.stderr[-600:]}", file=sys.stderr, flush=True)
+        except subprocess.TimeoutExpired:
+            print(f"bench[{rank}]: ipc preflight did not come back: the IPC transport is not a candidate on this node", file=sys.stderr, flush=True)
+        except Exception as ex:  # noqa: BLE001
+            print(f"bench[{rank}]: ipc preflight could not run: {ex!r}", file=sys.stderr, flush=True)
+        return agree_min_int(ok) == 1
+
     transport_ms = None
+    preflight = None
     if world > 1 and args.transport == "auto":
-        cands = ["ipc", "rccl"] if torch.distributed.get_backend() == "nccl" else ["ipc", "torch"]
+        # RCCL first: it is what north_star names, and its numbers are in hand before the IPC transport is let into this process
+        cands = ["rccl", "ipc"] if torch.distributed.get_backend() == "nccl" else ["torch", "ipc"]
         transport_ms, built = {}, {}
 
         def phase(c, fn):
@@ -511,6 +531,12 @@ def main():
 
         for c in cands:
             transport_ms[c] = None
+            if c == "ipc":
+                # (the rank grid the job will use: taken from the candidate built before, else the library's compact default)
+                g_ = next((b[1].get_num_ranks_vec() for b in built.values()), None)
+                preflight = ipc_preflight(g_) if g_ else None
+                if preflight is False:
+                    continue
             if not phase(c, lambda: built.__setitem__(c, build(c))):
                 if c in built:
                     built.pop(c)[1].end_solution()
@@ -707,6 +733,7 @@ def main():
                                            "weak": "one block per GPU"}[args.config] if not args.local else "explicit --points-per-gpu",
                        "decomposition": ("rank grid (--rank-grid) " if args.rank_grid else "x-slabs " if decomp == "xslab" else "compact rank grid ") + "x".join(str(g) for g in grid),
                        "halo_transport": transport, "transport_trials_ms_per_step": transport_ms, "self_check": self_check,
+                       "ipc_preflight_in_child_processes": preflight,
                        "kernel": "+".join(soln.get_kernel_variant(p) for p in range(nparts)),
                        "overlap_comms": (schedule != "serial") if world > 1 else None,
                        "schedule": schedule, "schedule_trials_ms_per_step": schedule_ms,

@@ -250,6 +250,8 @@ def test_bench_on_real_devices_with_its_self_check(n):
     assert sc["transports"] and all(v["ok"] for v in sc["transports"].values()), sc
     assert j["config"]["halo_transport"] in sc["transports"]
     assert sc["devices"] == (1 if DRYRUN else n)
+    # the IPC transport was let into the job's processes only after it had run in child processes (yask_amd/ipc_preflight.py)
+    assert j["config"]["ipc_preflight_in_child_processes"] is True or "ipc" not in sc["transports"]
     if j["config"]["halo_transport"] == "ipc":       # the host is out of the exchange loop: no registration travels during the timed steps
         cp = j["halo"]["ipc_control_plane_rank0"]
         assert cp["control_msgs_in_timed_region"] == 0 and cp["device_ops_per_step"] > 0
