@@ -226,7 +226,7 @@ def cpu_baseline():
             if "best" in r and r["best"] >= 2.0:
                 try:
                     t1 = time.time()
-                    tr = _ref_harness(exe, n, 50, 2, cores, 300, tuned=True)
+                    tr = _ref_harness(exe, n, 50, 2, cores, 180, tuned=True)      # (bounded: the whole bench line has to come within minutes)
                     if "best" in tr:
                         tuned = {"best": round(tr["best"], 4), "mid": round(tr.get("mid", tr["best"]), 4), "secs_incl_tuning": round(time.time() - t1, 1),
                                  "what": f"-pre_auto_tune -auto_tune_trial_secs 0.25 (the tuner's default of 0.5 s per candidate took 150 s at this size), 2 trials x 50 steps, {n}^3"}
