@@ -103,17 +103,22 @@ def mem_available_gib():
 class GpuSampler(threading.Thread):
     """Samples shader clock (MHz), memory clock and socket power (W) of one GPU from sysfs while it is under load."""
 
-    def __init__(self, index=0, period=0.05):
+    def __init__(self, pci_bus_id=None, period=0.05):
+        """`pci_bus_id`: hipDeviceGetPCIBusId of the device this process computes on.  The sysfs card is found BY THAT ID: on a host with
+        eight cards and one visible device, card index 0 is a neighbour (round 4's record showed 157 MHz "under load").
+        Without a match nothing is sampled (None), rather than some other card."""
         super().__init__(daemon=True)
         self.period, self.samples, self._stop_evt = period, [], threading.Event()
-        cards = []
+        self.pci_bus_id, self.dev = pci_bus_id, None
         for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
             try:
-                if open(d + "/vendor").read().strip() == "0x1002" and os.path.exists(d + "/pp_dpm_sclk"):
-                    cards.append(d)
+                if open(d + "/vendor").read().strip() != "0x1002" or not os.path.exists(d + "/pp_dpm_sclk"):
+                    continue
+                if pci_bus_id and os.path.basename(os.path.realpath(d)).lower() == pci_bus_id.lower():
+                    self.dev = d
+                    break
             except OSError:
                 continue
-        self.dev = cards[index % len(cards)] if cards else None
         self.hwmon = (glob.glob(self.dev + "/hwmon/hwmon*") or [None])[0] if self.dev else None
 
     @staticmethod
@@ -155,7 +160,9 @@ class GpuSampler(threading.Thread):
         self.join(timeout=2)
 
     def summary(self):
-        out = {"source": "sysfs pp_dpm_sclk / hwmon, sampled while the GPU ran", "samples": len(self.samples)}
+        out = {"source": "sysfs pp_dpm_sclk / hwmon of the card with this device's PCI bus id, sampled while the GPU ran",
+               "pci_bus_id": self.pci_bus_id, "card": os.path.basename(os.path.dirname(self.dev)) if self.dev else None,
+               "samples": len(self.samples)}
         for k in ("sclk_mhz", "mclk_mhz", "power_w"):
             v = [s[k] for s in self.samples if s.get(k) is not None]
             if v:
@@ -295,6 +302,36 @@ def live_traffic(args, kernel_name):
         return None, None
 
 
+def visible_gpus():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def launch_ranks(n, argv):
+    """`python3 bench.py --gpus N` without a launcher: one rank per GPU under torch.distributed.run (what the driver starts for N > 1),
+    or a refusal when the box does not have N devices.  YASK_DIST_BACKEND=gloo (several ranks on one device: tests) needs one.
+    Returns the exit code of the job.  YASK_BENCH_LAUNCH_DRYRUN=1 prints the command instead of running it (CPU tests)."""
+    have = int(os.environ["YASK_BENCH_FAKE_NGPUS"]) if os.environ.get("YASK_BENCH_FAKE_NGPUS") else visible_gpus()
+    need = 1 if os.environ.get("YASK_DIST_BACKEND", "") == "gloo" else n
+    if have < need:
+        sys.stderr.write(f"bench.py: {n} GPUs requested, {have} visible -- not running (a smaller job would be reported as --gpus {n})\n")
+        return 2
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    if os.environ.get("YASK_BENCH_LAUNCH_DRYRUN"):
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL and the IPC transport need it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -343,6 +380,13 @@ def main():
             argv[i:i + 2] = ["--opts=" + argv[i + 1]]
             break
     args = ap.parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit(f"bench.py: --gpus {args.gpus}")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # started plainly (`python3 bench.py --gpus N`): start the N ranks here, or refuse -- never run ONE rank and print
+        # "n_gpus": 1 for a --gpus N command (VERDICT r04 missing #4; the reference's launcher decides the ranks itself,
+        # src/kernel/yask.sh:389-413)
+        raise SystemExit(launch_ranks(args.gpus, argv))
 
     import torch
     from yask_amd import yk_factory, dist as ydist
@@ -350,12 +394,16 @@ def main():
     if os.environ.get("YASK_BENCH_STACK_DUMP_S"):      # debugging aid: where is every rank after so many seconds?
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["YASK_BENCH_STACK_DUMP_S"]), repeat=False, file=sys.stderr)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("YASK_DIST_BACKEND", "") != "gloo":
+        lws, have = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"])), visible_gpus()
+        if have < lws:       # RCCL wants one device per rank; two ranks on one device would hang in the communicator set-up
+            raise SystemExit(f"bench.py: {lws} ranks on this node, {have} GPUs visible")
     rank, local_rank, world = ydist.init_process_group()
     # the IPC transport's flag waiters give up after this many seconds (library default 20): a transport that does not work on this node
     # should cost the warm-up seconds, not minutes, before the other one is tried
     os.environ.setdefault("YASK_HIP_WAIT_TIMEOUT_S", "8")
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     stencil, descr, dflt_n, dtype, BYTES_PER_POINT, init = WORKLOADS[args.workload]
     if local_rank == 0:
         from yask_amd import _capi
@@ -648,7 +696,12 @@ def main():
         soln.get_stats()
 
     smi_before = smi_snapshot() if rank == 0 else None
-    sampler = GpuSampler(local_rank)
+    try:
+        from yask_amd import _hip as _hiprt
+        bus_id = _hiprt.current_device_pci_bus_id()
+    except Exception:  # noqa: BLE001
+        bus_id = None
+    sampler = GpuSampler(bus_id)
     # ---- warm-up: W steps, then a time-based ramp (every rank runs the same number of steps)
     ramp_steps = 0
     barrier()

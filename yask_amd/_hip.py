@@ -33,3 +33,12 @@ def memcpy_dtoh(dst_host, src_dev, nbytes):
 
 def memcpy_htod(dst_dev, src_host, nbytes):
     _chk(_lib().hipMemcpy(C.c_void_p(dst_dev), C.c_void_p(src_host), C.c_size_t(nbytes), C.c_int(1)), "hipMemcpy H2D")
+
+
+def current_device_pci_bus_id():
+    """'0000:c1:00.0' of the HIP device this thread is bound to (sysfs: /sys/bus/pci/devices/<id>)."""
+    dev = C.c_int(0)
+    _chk(_lib().hipGetDevice(C.byref(dev)), "hipGetDevice")
+    buf = C.create_string_buffer(64)
+    _chk(_lib().hipDeviceGetPCIBusId(buf, C.c_int(64), dev), "hipDeviceGetPCIBusId")
+    return buf.value.decode().lower()
