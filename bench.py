@@ -302,6 +302,19 @@ def live_traffic(args, kernel_name):
         return None, None
 
 
+def placement_report(pl, step_ms):
+    """the placement search's own number for the set it kept (mean of 6 back-to-back steps, library) next to what the timed region then
+    measured per step: the two must agree, or the search is buying nothing (VERDICT r04 weak #7)"""
+    if not pl:
+        return pl
+    out = dict(pl)
+    out["kept_ms"] = pl["ms_per_step_of_each_set"][pl["kept"]]
+    if step_ms:
+        out["timed_region_median_ms"] = round(statistics.median(step_ms), 4)
+        out["timed_over_kept"] = round(statistics.median(step_ms) / out["kept_ms"], 4) if out["kept_ms"] > 0 else None
+    return out
+
+
 def visible_gpus():
     import torch
     return torch.cuda.device_count() if torch.cuda.is_available() else 0
@@ -500,22 +513,26 @@ def main():
             torch.distributed.gather_object(boxes, gathered, dst=0)
             same = 1
             if rank == 0:
-                one = fac.new_solution(fac.new_env())
-                one.set_overall_domain_size_vec(gsz)
-                assert one.apply_command_line_options(CHECK_KERNEL[stencil]) == ""
-                one.prepare_solution()
-                for nm, (off, sc, hid) in init.items():
-                    one.get_var(nm).set_elements_hash(off, sc, hash_id=hid)
-                one.run_solution(0, steps_c - 1)
-                for f, l, arrs in gathered:
-                    for nm, a in arrs.items():
-                        ref = one.get_var(nm).get_elements_in_slice([steps_c] + f, [steps_c] + l)[0]
-                        if not np.array_equal(a, ref):
-                            same = 0
-                            print(f"bench: self-check of '{name}' / {sched}: box {f}..{l} of '{nm}' differs from the one-rank run "
-                                  f"(max abs diff {float(np.abs(a.astype(np.float64) - ref).max()):.3e})", file=sys.stderr, flush=True)
-                one.end_solution()
-                del one
+                try:                # (an exception here must not leave the other ranks waiting in the all-reduce below: ADVICE r04)
+                    one = fac.new_solution(fac.new_env())
+                    one.set_overall_domain_size_vec(gsz)
+                    assert one.apply_command_line_options(CHECK_KERNEL[stencil]) == ""
+                    one.prepare_solution()
+                    for nm, (off, sc, hid) in init.items():
+                        one.get_var(nm).set_elements_hash(off, sc, hash_id=hid)
+                    one.run_solution(0, steps_c - 1)
+                    for f, l, arrs in gathered:
+                        for nm, a in arrs.items():
+                            ref = one.get_var(nm).get_elements_in_slice([steps_c] + f, [steps_c] + l)[0]
+                            if not np.array_equal(a, ref):
+                                same = 0
+                                print(f"bench: self-check of '{name}' / {sched}: box {f}..{l} of '{nm}' differs from the one-rank run "
+                                      f"(max abs diff {float(np.abs(a.astype(np.float64) - ref).max()):.3e})", file=sys.stderr, flush=True)
+                    one.end_solution()
+                    del one
+                except Exception as ex:  # noqa: BLE001
+                    same = 0
+                    print(f"bench: self-check of '{name}' / {sched}: the one-rank reference failed to run: {ex!r}", file=sys.stderr, flush=True)
             same = agree_min_int(same)
             rec["schedules"][sched] = "bit-identical to one rank" if same else "DIFFERS from one rank"
             all_ok = all_ok and bool(same)
@@ -542,10 +559,26 @@ def main():
     # timed steps on the default schedule, the times are max-reduced over the ranks, the faster one runs the benchmark and both
     # numbers are reported.  A candidate that cannot be set up on every rank, fails the self-check or its trial, is skipped (and
     # reported).  Every rank issues the same sequence of collectives whether or not a phase failed locally.
+    def job_rank_grid():
+        if args.rank_grid:
+            return list(args.rank_grid)
+        if decomp == "xslab":
+            return [world, 1, 1]
+        import ctypes as C
+        from yask_amd import _capi
+        pl = _capi.RankPlan()
+        per_rank = list(args.local) if args.local else [n, n, n // 2] if args.config == "c4" else [n, n, n] if args.config == "weak" else None
+        for d in range(3):      # (the same settings build() gives the solution)
+            pl.global_size[d], pl.local_size[d], pl.num_ranks[d] = (0, per_rank[d], 0) if per_rank else (n, 0, 0)
+        if _capi.load(stencil).yk_plan_rank(3, world, rank, C.byref(pl)) != 0:
+            raise SystemExit("bench.py: the rank grid of this job cannot be planned")
+        return [int(pl.num_ranks[d]) for d in range(3)]
+
     def ipc_preflight(grid_):
         """the IPC transport in a CHILD process first (yask_amd/ipc_preflight.py): a transport whose set-up or first exchanges hang on
         this node hangs a child that can be killed, not this job.  True only if every rank's child came back with exit code 0."""
-        child_env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 300), PYTHONPATH=str(ROOT))
+        child_env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 300),
+                         PYTHONPATH=os.pathsep.join([str(ROOT)] + [x for x in os.environ.get("PYTHONPATH", "").split(os.pathsep) if x]))
         child_env.pop("YASK_BENCH_STACK_DUMP_S", None)
         ok = 0
         try:
@@ -581,9 +614,10 @@ def main():
             transport_ms[c] = None
             if c == "ipc":
                 # (the rank grid the job will use: taken from the candidate built before, else the library's compact default)
-                g_ = next((b[1].get_num_ranks_vec() for b in built.values()), None)
-                preflight = ipc_preflight(g_) if g_ else None
-                if preflight is False:
+                # (the rank grid the job will use, from the same planning code prepare_solution() runs -- not from another candidate:
+                #  with none built the IPC transport would otherwise enter this process unguarded)
+                preflight = ipc_preflight(job_rank_grid())
+                if not preflight:
                     continue
             if not phase(c, lambda: built.__setitem__(c, build(c))):
                 if c in built:
@@ -790,7 +824,7 @@ def main():
                        "kernel": "+".join(soln.get_kernel_variant(p) for p in range(nparts)),
                        "overlap_comms": (schedule != "serial") if world > 1 else None,
                        "schedule": schedule, "schedule_trials_ms_per_step": schedule_ms,
-                       "var_placement": soln.get_placement_trials(),
+                       "var_placement": placement_report(soln.get_placement_trials(), step_ms),
                        "yask_options": args.opts, "fused_two_step_passes_in_timed_region": st.get_num_fused_passes(),
                        "ramp_steps_untimed": ramp_steps},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

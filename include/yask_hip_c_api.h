@@ -263,6 +263,22 @@ yk_idx_t yk_solution_get_kernel_variant_scratch_bytes(yk_soln_h s, int part, int
  * such a box, 0 if it is unconditional (first/last = the rank's domain), 2 if the condition holds nowhere in this
  * rank (first > last), -1 on error. */
 int yk_solution_get_part_bounding_box(yk_soln_h s, int part, yk_idx_t* first, yk_idx_t* last);
+/* Work of one stencil part, per step on this rank -- the facts the reference prints per part and stage in
+ * Stage::init_work_stats (src/kernel/lib/stencil_calc.cpp:461-598: points to eval, reads / writes / est FP-ops per point, the
+ * input / output var lists), plus what a bandwidth-bound GPU kernel is measured against: the COMPULSORY HBM bytes per point =
+ * (distinct arrays read + arrays written) x element size, where an array is one (var, step offset, misc indices) access group of
+ * a var that spans every domain dim of the solution (lower-dimensional vars -- coefficient lines, sponge profiles -- stay in
+ * cache and count 0) and scratch vars are left out (a cost of this implementation, reported separately).  tools/generic_table.py. */
+typedef struct {
+    const char* name;
+    int stage, is_scratch, has_condition;
+    int fp_ops, points_read, points_written;          /* per point, as the reference reports them */
+    int arrays_read, arrays_written;                  /* full-dimensional, non-scratch */
+    int scratch_arrays_read, scratch_arrays_written;
+    yk_idx_t points;                                  /* points one step evaluates (sub-domain box clipped to this rank, x outer dim) */
+    double compulsory_bytes_per_point;
+} yk_part_info_t;
+int yk_solution_get_part_info(yk_soln_h s, int part, yk_part_info_t* out);
 /* Launch part `part` of step t once with variant i (or the selected one if i < 0) on the compute
  * stream, bracketed by HIP events; returns the kernel duration in ms in *ms. Used by bench.py. */
 int yk_solution_time_part(yk_soln_h s, int part, int variant, yk_idx_t xchunk, yk_idx_t t, int reps, float* ms);

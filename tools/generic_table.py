@@ -1,0 +1,136 @@
+#!/usr/bin/env python
+"""A roofline for EVERY solution the cdna4_hip target renders.
+
+For each solution: the default size of its dimensionality, default options (what a user of the library gets), hashed O(1) data, then
+  * per step: median of the per-step HIP events (-hip_step_timers) over `--steps` steps  ->  Gpoints/s (domain points per second),
+    compulsory GB/s = sum over parts of points(part) x compulsory bytes per point (yk_solution_get_part_info: distinct full-dimensional
+    arrays read + written x element size, scratch vars left out) / step time, and that as a fraction of the 8 TB/s HBM peak;
+  * per part: the kernel family that runs it (`yk_solution_get_kernel_variant`), its own time (yk_solution_time_part, 5 launches), its
+    compulsory GB/s and fraction.
+The facts are the ones the reference prints in Stage::init_work_stats (src/kernel/lib/stencil_calc.cpp:461-598); the list of solutions
+is the reference's test matrix (src/kernel/Makefile:1101-1182).  Writes <out>/table.json and <out>/table.md.
+
+    python tools/generic_table.py --out gpurun_out/r5_generic [--only fsg ssg2] [--size3 256] [--big 512]"""
+import argparse
+import json
+import statistics
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+HBM_PEAK_GBS = 8000.0
+
+
+def family(variant):
+    return variant.split("_")[0] if variant else "?"
+
+
+def run_one(stencil, sizes, steps, opts=""):
+    from yask_amd import yk_factory
+    from yask_amd.kernel import yk_env
+    yk_env.disable_debug_output()
+    fac = yk_factory(stencil)
+    env = fac.new_env()
+    soln = fac.new_solution(env)
+    dims = soln.get_domain_dim_names()
+    size = sizes[len(dims)]
+    for d, n in zip(dims, size):
+        soln.set_overall_domain_size(d, n)
+    rem = soln.apply_command_line_options("-hip_step_timers " + opts)
+    assert rem == "", rem
+    soln.prepare_solution()
+    for k, v in enumerate(soln.get_vars()):
+        v.set_elements_hash(1.0 + 0.25 * k, 0.1, hash_id=k)
+    soln.run_solution(0, 1)                     # warm-up
+    soln.run_solution(2, 2 + steps - 1)
+    ms = soln.get_step_times()
+    step_ms = statistics.median(ms) if ms else float("nan")
+    eb = soln.get_element_bytes()
+    pts_domain = 1
+    for n in size:
+        pts_domain *= n
+    parts, step_bytes, step_scratch_bytes = [], 0.0, 0.0
+    for p in range(soln.get_num_parts()):
+        pi = soln.get_part_info(p)
+        var = soln.get_kernel_variant(p)
+        try:
+            soln.time_part(p, reps=1, t=100)
+            pms = soln.time_part(p, reps=5, t=101)
+        except RuntimeError as ex:               # (a part that cannot be launched on its own: reported without a time)
+            pms = None
+            print(f"  {stencil} part {p}: {ex}", file=sys.stderr)
+        b = pi["points"] * pi["compulsory_bytes_per_point"]
+        sb = pi["points"] * (pi["scratch_arrays_read"] + pi["scratch_arrays_written"]) * eb
+        step_bytes += b
+        step_scratch_bytes += sb
+        gbs = b / (pms * 1e-3) / 1e9 if pms and pms > 0 else None
+        parts.append({"part": p, "name": pi["name"], "stage": pi["stage"], "scratch": bool(pi["is_scratch"]), "condition": bool(pi["has_condition"]),
+                      "kernel": var, "family": family(var), "points": pi["points"], "arrays_read": pi["arrays_read"], "arrays_written": pi["arrays_written"],
+                      "scratch_arrays": pi["scratch_arrays_read"] + pi["scratch_arrays_written"], "fp_ops_per_point": pi["fp_ops"],
+                      "bytes_per_point": pi["compulsory_bytes_per_point"], "ms": round(pms, 4) if pms else None,
+                      "compulsory_gbs": round(gbs, 1) if gbs else None, "frac": round(gbs / HBM_PEAK_GBS, 4) if gbs else None})
+    rec = {"stencil": stencil, "size": list(size), "elem_bytes": eb, "steps": len(ms), "step_ms": round(step_ms, 4),
+           "gpoints_per_s": round(pts_domain / (step_ms * 1e-3) / 1e9, 3), "compulsory_bytes_per_step": step_bytes,
+           "scratch_bytes_per_step": step_scratch_bytes,
+           "compulsory_gbs": round(step_bytes / (step_ms * 1e-3) / 1e9, 1), "frac": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "sum_part_ms": round(sum(p["ms"] or 0 for p in parts), 4), "parts": parts}
+    soln.end_solution()
+    return rec
+
+
+def markdown(recs, title):
+    out = [f"# {title}", "",
+           "`frac` = compulsory HBM bytes per step / step time / 8 TB/s (compulsory = distinct full-dimensional arrays read + written x element",
+           "size, per part, over the part's own box; scratch vars and lower-dimensional coefficient arrays count 0).  Step time = median of",
+           "per-step HIP events, default options; `families` = kernel family of every part (`starlin` / `march` = marching kernels with a",
+           "register x-queue, `star25d` = 2.5-D LDS slab, `vecpt` = 16-byte vector point kernel, `naive` = one point per thread).", "",
+           "| solution | size | parts | step ms | Gpoints/s | compulsory GB/s | frac | families | worst part (frac) |",
+           "|---|---|---|---|---|---|---|---|---|"]
+    for r in recs:
+        if "error" in r:
+            out.append(f"| {r['stencil']} | | | | | | | | {r['error'][:80]} |")
+            continue
+        fams = {}
+        for p in r["parts"]:
+            fams[p["family"]] = fams.get(p["family"], 0) + 1
+        timed = [p for p in r["parts"] if p["frac"] is not None and p["points"] * 8 >= max(q["points"] for q in r["parts"])]
+        worst = min(timed, key=lambda p: p["frac"]) if timed else None
+        out.append(f"| {r['stencil']} | {'x'.join(str(n) for n in r['size'])} | {len(r['parts'])} | {r['step_ms']} | {r['gpoints_per_s']} | {r['compulsory_gbs']} | "
+                   f"**{r['frac']}** | {', '.join(f'{k} x{v}' if v > 1 else k for k, v in sorted(fams.items()))} | "
+                   + (f"{worst['part']} `{worst['name']}` on `{worst['kernel']}` ({worst['frac']})" if worst else "") + " |")
+    return "\n".join(out) + "\n"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "r5_generic"))
+    ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--size3", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--opts", default="")
+    ap.add_argument("--tag", default="table")
+    args = ap.parse_args()
+    import __graft_entry__ as G
+    names = args.only or [s for s in G.STENCILS if s not in ("3axis_r1", "wave2d_f64")] + ["3axis_r1", "wave2d_f64"]
+    n3 = args.size3
+    sizes = {1: [1 << 24], 2: [4096, 4096], 3: [n3, n3, n3], 4: [16, n3 // 2, n3 // 2, n3 // 2]}
+    out = Path(args.out)
+    out.mkdir(parents=True, exist_ok=True)
+    recs = []
+    for s in names:
+        t0 = time.perf_counter()
+        try:
+            r = run_one(s, sizes, args.steps, args.opts)
+        except Exception as ex:  # noqa: BLE001
+            r = {"stencil": s, "error": repr(ex)}
+        r["wall_s"] = round(time.perf_counter() - t0, 2)
+        recs.append(r)
+        print(s, r.get("step_ms"), r.get("frac"), r.get("error", ""), flush=True)
+        (out / f"{args.tag}.json").write_text(json.dumps(recs, indent=1))
+    (out / f"{args.tag}.md").write_text(markdown(recs, f"Every renderable solution at {n3}^3 (2-D: 4096^2, 1-D: 2^24, 4-D: 16 x {n3 // 2}^3) on one MI355X, default options"))
+
+
+if __name__ == "__main__":
+    main()

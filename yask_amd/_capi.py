@@ -51,6 +51,13 @@ class BlockDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("x0", "x1", "y0", "y1", "z0", "z1", "flags", "start")]
 
 
+class PartInfo(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("stage", C.c_int), ("is_scratch", C.c_int), ("has_condition", C.c_int),
+                ("fp_ops", C.c_int), ("points_read", C.c_int), ("points_written", C.c_int),
+                ("arrays_read", C.c_int), ("arrays_written", C.c_int), ("scratch_arrays_read", C.c_int), ("scratch_arrays_written", C.c_int),
+                ("points", C.c_longlong), ("compulsory_bytes_per_point", C.c_double)]
+
+
 class RankPlan(C.Structure):
     """yk_rank_plan_t"""
     _fields_ = [("global_size", idx_t * 3), ("local_size", idx_t * 3), ("num_ranks", idx_t * 3), ("rank_index", idx_t * 3),
@@ -155,6 +162,7 @@ PROTOTYPES = {
     "yk_solution_get_kernel_variant": (_S, [_H, C.c_int]),
     "yk_solution_get_num_kernel_variants": (C.c_int, [_H, C.c_int]),
     "yk_solution_get_kernel_variant_name": (_S, [_H, C.c_int, C.c_int]),
+    "yk_solution_get_part_info": (C.c_int, [_H, C.c_int, C.POINTER(PartInfo)]),
     "yk_solution_time_part": (C.c_int, [_H, C.c_int, C.c_int, idx_t, idx_t, C.c_int, C.POINTER(C.c_float)]),
     "yk_solution_time_decomposed_step": (C.c_int, [_H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_float)]),
     "yk_solution_time_part_box": (C.c_int, [_H, C.c_int, C.c_int, idx_t, _IP, _IP, idx_t, C.c_int, C.POINTER(C.c_float)]),

@@ -266,7 +266,7 @@ yk_idx_t yk_solution_get_last_rank_domain_index(yk_soln_h s, const char* dim) {
 }
 int yk_solution_run(yk_soln_h s, yk_idx_t a, yk_idx_t b) { YK_TRY S(s).run(a, b); return 0; YK_CATCH(1) }
 int yk_solution_end(yk_soln_h s) { YK_TRY S(s).end(); return 0; YK_CATCH(1) }
-int yk_solution_exchange_halos(yk_soln_h s) { YK_TRY S(s).exchange_halos_all(); S(s).synchronize(); return 0; YK_CATCH(1) }
+int yk_solution_exchange_halos(yk_soln_h s) { YK_TRY S(s).exchange_halos_all(); S(s).synchronize(); S(s).check_async_errors("exchange_halos()", false); return 0; YK_CATCH(1) }
 int yk_solution_copy_vars_to_device(yk_soln_h s) { YK_TRY S(s).copy_vars_to_device(); return 0; YK_CATCH(1) }
 int yk_solution_copy_vars_from_device(yk_soln_h s) { YK_TRY S(s).copy_vars_from_device(); return 0; YK_CATCH(1) }
 int yk_solution_get_stats(yk_soln_h s, yk_stats_t* out) {
@@ -424,6 +424,38 @@ int yk_solution_get_part_bounding_box(yk_soln_h s, int part, yk_idx_t* first, yk
     for (int d = 0; d < 3; d++) { first[d] = d < MAX_DOMAIN_DIMS ? b.lo[d] : 0; last[d] = d < MAX_DOMAIN_DIMS ? b.hi[d] - 1 : 0; }
     return !has ? 0 : (b.empty() ? 2 : 1);
     YK_CATCH(-1)
+}
+int yk_solution_get_part_info(yk_soln_h s, int part, yk_part_info_t* out) {
+    YK_TRY
+    Solution& so = S(s);
+    if (part < 0 || part >= (int)so.impl.parts.size() || !out) YKH_THROW("part index out of range");
+    if (!so.prepared) YKH_THROW("get_part_info() called without calling prepare_solution() first");
+    const PartMeta& pm = *so.impl.parts[part].meta;
+    std::memset(out, 0, sizeof(*out));
+    out->name = pm.name; out->stage = pm.stage; out->is_scratch = pm.is_scratch;
+    out->has_condition = pm.has_domain_cond || pm.has_step_cond || pm.has_step_cond_dev;
+    out->fp_ops = pm.fp_ops; out->points_read = pm.points_read; out->points_written = pm.points_written;
+    std::vector<char> rd(pm.n_groups, 0), wr(pm.n_groups, 0);
+    for (int i = 0; i < pm.n_reads; i++) rd[pm.reads[i].g] = 1;
+    for (int i = 0; i < pm.n_writes; i++) wr[pm.writes[i]] = 1;
+    const int ndom = so.ndd + (so.has_outer ? 1 : 0);
+    for (int g = 0; g < pm.n_groups; g++) {
+        const VarMeta& vm = so.meta->vars[pm.groups[g].var];
+        int nd = 0;
+        for (int d = 0; d < vm.ndims; d++) { const int ty = so.meta->dims[vm.dims[d]].type; nd += ty == DIM_DOMAIN || ty == DIM_OUTER; }
+        if (nd < ndom) continue;                       // a line or plane of coefficients: cache-resident
+        if (vm.is_scratch) { out->scratch_arrays_read += rd[g]; out->scratch_arrays_written += wr[g]; }
+        else { out->arrays_read += rd[g]; out->arrays_written += wr[g]; }
+    }
+    const bool has = (size_t)part < so.part_has_bb.size() && so.part_has_bb[part];
+    const Box b = has ? so.part_bb[part] : so.rank_box();
+    yk_idx_t pts = b.empty() ? 0 : 1;
+    for (int d = 0; d < so.ndd && pts; d++) pts *= b.hi[d] - b.lo[d];
+    if (so.has_outer) pts *= so.local_size[3];
+    out->points = pts;
+    out->compulsory_bytes_per_point = (double)(out->arrays_read + out->arrays_written) * so.elem_bytes();
+    return 0;
+    YK_CATCH(1)
 }
 int yk_solution_time_part(yk_soln_h s, int part, int variant, yk_idx_t xchunk, yk_idx_t t, int reps, float* ms) {
     YK_TRY

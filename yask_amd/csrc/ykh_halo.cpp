@@ -44,6 +44,7 @@ static bool slab_for(const Solution& s, const Var& v, const Solution::Neighbor& 
 }
 
 void Solution::alloc_halo_buffers() {
+    halo_built_direct_ok = env->direct_halo_ok;
     if (env->nranks <= 1) return;
     for (auto& nb : neighbors) {
         auto x = std::make_unique<NeighborXfer>();
@@ -85,6 +86,9 @@ void Solution::alloc_halo_buffers() {
                 const Var& v = *vars[sl.var];
                 if (!(v.uses_domain[0] && v.uses_domain[1] && v.uses_domain[2]) || v.l1_norm > 1 || v.misc_elems != 1)
                     x->direct = false;
+                // an in-place message is named (HaloMsg::key) by solution ordinal, var and step slot in fixed fields of 16 slots and
+                // 255 vars: anything wider takes the packed path (one message per neighbour) instead of a colliding key
+                if (v.nslots > 16 || sl.var >= 255) x->direct = false;
             }
         for (size_t i = 0; x->direct && i < x->send.size(); i++)
             if (x->send[i].var != x->recv[i].var) x->direct = false;      // asymmetric halos: keep the packed path
@@ -283,6 +287,14 @@ void Solution::exchange_halos_all() {
     // reference's set_all_neighbor_vars_dirty() (context.cpp:234, halo.cpp:84-161 keeps self/others flags).
     for (auto& v : vars) v->before_device_use();      // raw buffers handed out: the caller may have written through them
     exch_half_ = -1;                                   // whole faces
+    if (env->nranks > 1 && halo_built_direct_ok != env->direct_halo_ok) {
+        // a transport was installed after prepare_solution() and it differs in whether peers may map var storage: the in-place
+        // x transfers were decided for the old one (every rank installs the same transport, so every rank rebuilds here)
+        free_halo_buffers();
+        alloc_halo_buffers();
+        drop_step_graphs();
+        drop_launch_plans();
+    }
     if (env->nranks > 1 && !xfers.empty() && env->exch_begin && env->exch_begin(env->user) != 0)
         YKH_THROW("halo-exchange transport failed to agree on its state across the ranks");
     if (env->nranks > 1)

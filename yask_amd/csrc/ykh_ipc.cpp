@@ -42,10 +42,15 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "../../include/yask_hip_c_api.h"
 #include "ykh_handles.hpp"
@@ -98,6 +103,7 @@ struct IpcState {
     std::vector<const unsigned*> wait_ptr;       // per message of the exchange in flight: its `ready` word ...
     std::vector<unsigned> wait_val;              // ... and the epoch it must reach
     long long ctl_msgs = 0, ctl_bytes = 0, begins = 0, resets = 0, dev_ops = 0;
+    double open_limit_s() const { return timeout_s * 2 > 20.0 ? timeout_s * 2 : 20.0; }      // mapping a peer's allocation: see open_guarded()
     unsigned* err() const { return mailbox + mailbox_words - 1; }
     unsigned* word(unsigned* box, int peer, int chan, int kind) const { return box + ((size_t)peer * CHANS + chan) * 2 + kind; }
 };
@@ -119,13 +125,40 @@ bool export_buf(IpcState* st, void* p, hipIpcMemHandle_t* h, unsigned long long*
     *room = (unsigned long long)size - *off;
     return true;
 }
+// hipIpcOpenMemHandle() with a time limit.  The call has been seen to NEVER return (two processes mapping each other's multi-GB
+// allocations at the same instant; tools/microbench/ipc_open.hip is the stand-alone probe): it runs on a helper
+// thread, and a caller that has waited `limit_s` gets hipErrorNotReady -- an exception in the host instead of a hung job.  The helper
+// of a call that timed out is abandoned (the job is failing anyway); a normal open costs one thread start (~50 us, first use of a
+// channel only).
+hipError_t open_guarded(void** base, const hipIpcMemHandle_t& h, double limit_s) {
+    struct Job { std::mutex m; std::condition_variable cv; bool done = false; hipError_t rc = hipErrorUnknown; void* base = nullptr; hipIpcMemHandle_t h; int dev = 0; };
+    auto job = std::make_shared<Job>();
+    job->h = h;
+    (void)hipGetDevice(&job->dev);
+    std::thread([job] {
+        void* b = nullptr;
+        hipError_t rc = hipSetDevice(job->dev);
+        if (rc == hipSuccess) rc = hipIpcOpenMemHandle(&b, job->h, hipIpcMemLazyEnablePeerAccess);
+        if (rc != hipSuccess) (void)hipGetLastError();
+        std::lock_guard<std::mutex> g(job->m);
+        job->rc = rc; job->base = b; job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(job->m);
+    if (!job->cv.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return job->done; })) return hipErrorNotReady;
+    *base = job->base;
+    return job->rc;
+}
+const char* open_error(hipError_t rc) { return rc == hipErrorNotReady ? "hipIpcOpenMemHandle did not return within the time limit (YASK_HIP_WAIT_TIMEOUT_S)" : hipGetErrorString(rc); }
+
 void* import_buf(IpcState* st, int peer, const hipIpcMemHandle_t& h) {
     std::string key = std::to_string(peer) + ":" + std::string((const char*)&h, sizeof(h));
     auto it = st->opened.find(key);
     if (it != st->opened.end()) return it->second;
     void* base = nullptr;
-    if (hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
-        fprintf(stderr, "yask ipc transport: rank %d cannot map a buffer of rank %d: %s\n", st->rank, peer, hipGetErrorString(hipGetLastError()));
+    const hipError_t rc = open_guarded(&base, h, st->open_limit_s());
+    if (rc != hipSuccess) {
+        fprintf(stderr, "yask ipc transport: rank %d cannot map a buffer of rank %d: %s\n", st->rank, peer, open_error(rc));
         return nullptr;
     }
     st->opened.emplace(key, base);
@@ -382,15 +415,17 @@ void ipc_free(void* p) {
 unsigned* map_host_mailbox(const char* name, size_t bytes, bool create, void** host_out) {
     const int fd = shm_open(name, create ? (O_CREAT | O_TRUNC | O_RDWR) : O_RDWR, 0600);
     if (fd < 0) return nullptr;
-    if (create && ftruncate(fd, (off_t)bytes) != 0) { ::close(fd); return nullptr; }
+    // (a segment this call created and cannot use must not stay behind in /dev/shm)
+    if (create && ftruncate(fd, (off_t)bytes) != 0) { ::close(fd); (void)shm_unlink(name); return nullptr; }
     void* h = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     ::close(fd);
-    if (h == MAP_FAILED) return nullptr;
+    if (h == MAP_FAILED) { if (create) (void)shm_unlink(name); return nullptr; }
     if (create) std::memset(h, 0, bytes);
     void* d = nullptr;
     if (hipHostRegister(h, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d) {
         (void)hipGetLastError();
         (void)munmap(h, bytes);
+        if (create) (void)shm_unlink(name);
         return nullptr;
     }
     *host_out = h;
@@ -405,12 +440,15 @@ int yk_env_init_ipc(yk_env_h e, int rank, int nranks, const char* addr, int base
     try {
         if (!e) return 1;
         e->env->set_ranks(rank, nranks);
-        auto* st = new IpcState;
+        // every failing return below releases what was built so far (mesh sockets, mailbox, the shm segment's NAME, peers' mailboxes
+        // already mapped): the state is owned by this guard until the transport is installed
+        struct Guard { IpcState* st; ~Guard() { if (st) ipc_free(st); } } guard{new IpcState};
+        IpcState* st = guard.st;
         st->rank = rank; st->nranks = nranks;
         if (const char* t = getenv("YASK_HIP_WAIT_TIMEOUT_S")) { const double v = atof(t); if (v > 0) st->timeout_s = v; }
         if (const char* t = getenv("YASK_HIP_IPC_VERBOSE")) st->verbose = atoi(t);
         st->mesh = tcp_connect_mesh(rank, nranks, addr && *addr ? addr : "127.0.0.1", base_port);
-        if (!st->mesh) { fprintf(stderr, "yask ipc transport: rank %d could not connect the control mesh\n", rank); delete st; return 1; }
+        if (!st->mesh) { fprintf(stderr, "yask ipc transport: rank %d could not connect the control mesh\n", rank); return 1; }
         st->next_chan.assign(nranks, 0);
         // ---- which device does every rank sit on?  (bus ids through rank 0's all-reduce-free mesh: pairwise, lower rank first)
         MailboxAd mine{};
@@ -494,9 +532,9 @@ int yk_env_init_ipc(yk_env_h e, int rank, int nranks, const char* addr, int base
                 return 1;
             }
             void* base = nullptr;
-            if (hipIpcOpenMemHandle(&base, theirs[p].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
-                fprintf(stderr, "yask ipc transport: rank %d cannot map the mailbox of rank %d: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)\n", rank, p,
-                        hipGetErrorString(hipGetLastError()));
+            const hipError_t orc = open_guarded(&base, theirs[p].handle, st->open_limit_s());
+            if (orc != hipSuccess) {
+                fprintf(stderr, "yask ipc transport: rank %d cannot map the mailbox of rank %d: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)\n", rank, p, open_error(orc));
                 return 1;
             }
             st->peer_mailbox[p] = (unsigned*)base;
@@ -507,6 +545,11 @@ int yk_env_init_ipc(yk_env_h e, int rank, int nranks, const char* addr, int base
         if (e->env->trace || getenv("YASK_HIP_IPC_VERBOSE"))
             fprintf(stderr, "yask ipc transport: rank %d of %d up on device %s (%s), mailbox in %s memory\n", rank, nranks, mine.busid,
                     st->multi_device ? "job spans devices" : "all ranks on this device", KIND_NAME[st->kind]);
+        // (no peer maps var storage unless asked to: YASK_HIP_IPC_DIRECT=1 brings the in-place x faces back, see Env::direct_halo_ok)
+        // -- and only when EVERY rank asks: a rank that packs facing one that maps would exchange different messages
+        long long direct = 0;
+        { const char* d = getenv("YASK_HIP_IPC_DIRECT"); direct = d && atoi(d) != 0; }
+        if (tcp_allreduce(st->mesh, 1, &direct) != 0) return 1;       // op 1 = min
         e->env->drop_transport();
         e->env->exch_start = ipc_start;
         e->env->exch_wait = ipc_wait;
@@ -514,11 +557,11 @@ int yk_env_init_ipc(yk_env_h e, int rank, int nranks, const char* addr, int base
         e->env->exch_begin = ipc_begin;
         e->env->exch_check = ipc_check;
         e->env->exch_counters = ipc_counters;
-        // (no peer maps var storage unless asked to: YASK_HIP_IPC_DIRECT=1 brings the in-place x faces back, see Env::direct_halo_ok)
-        { const char* d = getenv("YASK_HIP_IPC_DIRECT"); e->env->direct_halo_ok = d && atoi(d) != 0; }
+        e->env->direct_halo_ok = direct != 0;
         e->env->allreduce = ipc_allreduce;
         e->env->user = st;
         e->env->user_free = ipc_free;
+        guard.st = nullptr;
         return 0;
     } catch (...) { return 1; }
 }

@@ -69,11 +69,17 @@ int rccl_start(void* user, int n, const ykh::HaloMsg* m, void* stream) {
     RcclState* st = static_cast<RcclState*>(user);
     Rccl& r = rccl();
     NCCL_OK(r.GroupStart());
-    for (int i = 0; i < n; i++) {
-        if (m[i].recv_bytes) NCCL_OK(r.Recv(m[i].recv_buf, m[i].recv_bytes, NCCL_INT8, m[i].peer, st->comm, (hipStream_t)stream));
-        if (m[i].send_bytes) NCCL_OK(r.Send(m[i].send_buf, m[i].send_bytes, NCCL_INT8, m[i].peer, st->comm, (hipStream_t)stream));
+    // a failing send / recv must not leave the group open (the next exchange would nest inside it): remember the first error, stop
+    // queueing, and ALWAYS reach GroupEnd
+    int err = 0;
+    const char* where = "";
+    for (int i = 0; i < n && !err; i++) {
+        if (m[i].recv_bytes && (err = r.Recv(m[i].recv_buf, m[i].recv_bytes, NCCL_INT8, m[i].peer, st->comm, (hipStream_t)stream))) where = "ncclRecv";
+        if (!err && m[i].send_bytes && (err = r.Send(m[i].send_buf, m[i].send_bytes, NCCL_INT8, m[i].peer, st->comm, (hipStream_t)stream))) where = "ncclSend";
     }
-    NCCL_OK(r.GroupEnd());
+    int end = r.GroupEnd();
+    if (err) { fprintf(stderr, "RCCL error in %s: %s\n", where, r.GetErrorString(err)); return 1; }
+    if (end) { fprintf(stderr, "RCCL error in ncclGroupEnd: %s\n", r.GetErrorString(end)); return 1; }
     return 0;
 }
 int rccl_wait(void*, int, const ykh::HaloMsg*, void*) { return 0; }   // stream-ordered already
@@ -110,10 +116,17 @@ int yk_env_init_rccl(yk_env_h e, const void* id128, int rank, int nranks) {
         ncclUniqueId_t id;
         std::memcpy(&id, id128, sizeof(id));
         auto* st = new RcclState;
-        if (hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking) != hipSuccess) return 1;
-        if (hipMalloc(&st->dscalar, sizeof(long long)) != hipSuccess) return 1;
+        auto fail = [&](const char* what, const char* why) {
+            fprintf(stderr, "yk_env_init_rccl: %s failed%s%s\n", what, why ? ": " : "", why ? why : "");
+            if (st->dscalar) (void)hipFree(st->dscalar);
+            if (st->stream) (void)hipStreamDestroy(st->stream);
+            delete st;
+            return 1;
+        };
+        if (hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate", nullptr);
+        if (hipMalloc(&st->dscalar, sizeof(long long)) != hipSuccess) return fail("hipMalloc", nullptr);
         int rc = rccl().CommInitRank(&st->comm, nranks, id, rank);
-        if (rc != 0) { fprintf(stderr, "ncclCommInitRank failed: %s\n", rccl().GetErrorString(rc)); return 1; }
+        if (rc != 0) return fail("ncclCommInitRank", rccl().GetErrorString(rc));
         e->env->drop_transport();               // an earlier built-in transport
         e->env->exch_start = rccl_start;
         e->env->exch_wait = rccl_wait;

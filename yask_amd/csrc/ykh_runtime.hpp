@@ -533,6 +533,7 @@ public:
     void run_fused(idx_t t0, idx_t npairs, idx_t dir);
     void launch_fused(idx_t t, const void* src, void* slot_b, void* dst, bool store_b);
     void exchange_halos_all();
+    void check_async_errors(const char* who, bool sig_used);      // after the streams have drained
     Stats get_stats();       // returns and clears, like soln_apis.cpp:349-562
     void reset_auto_tuner(bool enable);
     void run_auto_tuner_now();
@@ -551,6 +552,7 @@ public:
     bool launching_exterior = false;      // set by run() around the exterior slabs of a decomposed run (thin-slab kernel choice)
     void launch_part_variant(int part, int variant, idx_t xchunk, idx_t t, const Box& box_in, hipStream_t s);
     void fill_part_args(int part, idx_t t, const Box& box, PartArgs& a) const;
+    bool halo_built_direct_ok = true;  // env->direct_halo_ok when alloc_halo_buffers() last ran
     void alloc_halo_buffers();
     void free_halo_buffers();
     void exchange_halos(idx_t t_written, int stage, bool start_only, bool finish_only);

@@ -141,6 +141,22 @@ void Solution::synchronize() {
     YKH_HIP(hipStreamSynchronize(comm_stream));
 }
 
+// Errors raised on the device while a call's work ran (a waiter that gave up): turned into an exception by the call that queued the
+// work, once its streams have drained -- the error words are always consumed by the call that raised them, so that the next call
+// does not start with every wait returning at once (exchange_halos() used to return success with stale halos).
+void Solution::check_async_errors(const char* who, bool sig_used) {
+    if (sig_used && sig_dev) {
+        unsigned err = 0;
+        YKH_HIP(hipMemcpy(&err, sig_dev + 2, sizeof(err), hipMemcpyDeviceToHost));
+        if (err) {
+            (void)hipMemset(sig_dev + 2, 0, sizeof(unsigned));
+            YKH_THROW(std::string(who) + ": a halo exchange waited in vain for the shell blocks of a planned launch (device-side signal timed out)");
+        }
+    }
+    if (env->nranks > 1 && env->exch_check && env->exch_check(env->user) != 0)
+        YKH_THROW(std::string(who) + ": the halo transport reports a failed exchange");
+}
+
 int Solution::domain_dim_idx(const std::string& dim, const char* fn) const {
     for (int d = 0; d < ndd; d++)
         if (domain_dim_names[d] == dim) return d;
@@ -1063,16 +1079,7 @@ void Solution::run(idx_t first_step, idx_t last_step) {
     }
     YKH_HIP(hipStreamSynchronize(compute_stream));
     if (multi) YKH_HIP(hipStreamSynchronize(comm_stream));
-    if (sig_used && sig_dev) {
-        unsigned err = 0;
-        YKH_HIP(hipMemcpy(&err, sig_dev + 2, sizeof(err), hipMemcpyDeviceToHost));
-        if (err) {
-            (void)hipMemset(sig_dev + 2, 0, sizeof(unsigned));
-            YKH_THROW("run_solution(): a halo exchange waited in vain for the shell blocks of a planned launch (device-side signal timed out)");
-        }
-    }
-    if (multi && env->exch_check && env->exch_check(env->user) != 0)
-        YKH_THROW("run_solution(): the halo transport reports a failed exchange");
+    check_async_errors("run_solution()", sig_used);
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stats.elapsed_secs += secs;
     stats.halo_secs += halo_secs;

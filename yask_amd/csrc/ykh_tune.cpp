@@ -43,18 +43,22 @@ void Solution::tune_placement() {
     auto time_steps = [&]() -> float {
         // O(1) hashed values, no zeros (timed on zeroed arrays the ranking did not hold: all-zero data runs ~3 % faster)
         for (size_t k = 0; k < mv.size(); k++) mv[k]->set_elements_hash(1.0, 0.1, (int)k);
-        float ms_min = 0.f;
-        for (int r = 0; r <= 3; r++) {                 // r = 0: untimed (first touch of the new addresses)
-            YKH_HIP(hipEventRecord(ev.e0, compute_stream));
+        // What a caller's timed region sees is the MEAN of back-to-back steps between two events (launch gaps included), not the best
+        // single launch: round 4's driver run kept a set "measured at 2.874 ms" (best of three launches) and then stepped at 2.98
+        // (VERDICT r04 weak #7).  So: one untimed step (first touch of the new addresses), then TRIAL_STEPS steps inside ONE event pair.
+        constexpr int TRIAL_STEPS = 6;
+        auto one_step = [&](int r) {
             for (int st = 0; st < meta->n_stages; st++)
                 for (int k = 0; k < meta->stages[st].n_parts; k++) launch_part(meta->stages[st].parts[k], r, rb, compute_stream);
-            YKH_HIP(hipEventRecord(ev.e1, compute_stream));
-            YKH_HIP(hipEventSynchronize(ev.e1));
-            float ms = 0.f;
-            YKH_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
-            if (r > 0 && (ms_min == 0.f || ms < ms_min)) ms_min = ms;
-        }
-        return ms_min;
+        };
+        one_step(0);
+        YKH_HIP(hipEventRecord(ev.e0, compute_stream));
+        for (int r = 1; r <= TRIAL_STEPS; r++) one_step(r);
+        YKH_HIP(hipEventRecord(ev.e1, compute_stream));
+        YKH_HIP(hipEventSynchronize(ev.e1));
+        float ms = 0.f;
+        YKH_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+        return ms / TRIAL_STEPS;
     };
     // a set of allocations = (owner, alloc_ptr, dptr) per var; the vars always point at the set being timed; a set nobody
     // points at any more is freed when its owners go (Var::own_allocation)

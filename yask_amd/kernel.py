@@ -467,6 +467,16 @@ class yk_solution:
     def get_kernel_variant_names(self, part=0):
         n = self._lib.call("yk_solution_get_num_kernel_variants", self._h, part)
         return [self._lib.call("yk_solution_get_kernel_variant_name", self._h, part, i).decode() for i in range(n)]
+    def get_part_info(self, part=0):
+        """Work of one stencil part per step on this rank (the reference's per-part work stats, stencil_calc.cpp:461-598) and its
+        compulsory HBM bytes per point; dict of the fields of yk_part_info_t."""
+        from ._capi import PartInfo
+        pi = PartInfo()
+        self._lib.call_rc("yk_solution_get_part_info", self._h, int(part), C.byref(pi))
+        d = {k: getattr(pi, k) for k, _ in PartInfo._fields_}
+        d["name"] = d["name"].decode() if d["name"] else ""
+        return d
+
     def time_part(self, part=0, variant=-1, xchunk=0, t=0, reps=1):
         """Average HIP-event duration (ms) of `reps` launches of one stencil part."""
         ms = C.c_float(0)
