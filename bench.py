@@ -370,11 +370,11 @@ def main():
                     help="N>1: halo transport.  ipc: device-to-device copies through HIP IPC handles + stream-ordered flags; rccl: grouped "
                          "ncclSend/ncclRecv; torch: torch.distributed P2P (host-staged with gloo: tests).  auto (default): ipc and rccl each "
                          "run a few steps during warm-up, the faster one is used and both timings are reported")
-    ap.add_argument("--schedule", default="auto", choices=["auto", "planned", "planned35", "planned_inlinepack", "halves", "slabs", "serial"],
-                    help="N>1: how a step is issued.  planned / planned35: the rank box as ONE launch of equal blocks, shell blocks first (done "
-                         "after 55 / 35 %% of the launch), the halo exchange released from the device when they are done; slabs: "
-                         "exterior slabs, then the exchange beside the interior (round 2); serial: the whole box, "
-                         "then the exchange (-no-overlap_comms).  auto (default): every candidate runs a few steps during warm-up, "
+    ap.add_argument("--schedule", default="auto", choices=["auto", "halves", "planned", "slabs", "serial"],
+                    help="N>1: how a step is issued.  halves (the library's default): two launches in regular order, the outer and the inner half of "
+                         "the x range, each followed by the exchange of its part of the faces; planned: ONE plan of equal blocks, the blocks a "
+                         "neighbour needs first, the exchange released by an event behind their rounds; slabs: exterior slabs, then the exchange "
+                         "beside the interior; serial: the whole box, then the exchange (-no-overlap_comms).  auto (default): every candidate runs a few steps during warm-up, "
                          "the fastest (max over ranks) is used for the timed region and all timings are reported")
     ap.add_argument("--opts", default="", help="extra yask options, e.g. '-hip_variant NAME'")
     ap.add_argument("--no-self-check", action="store_true",
@@ -625,7 +625,7 @@ def main():
                 continue
             e_, s_, used_ = built[c]
             good = checked(c, e_, s_)
-            good = good and phase(c, lambda: (s_.apply_command_line_options("-overlap_comms -hip_planned_launch"), s_.run_solution(0, 1)))
+            good = good and phase(c, lambda: (s_.apply_command_line_options("-overlap_comms -hip_planned_launch -no-hip_halves"), s_.run_solution(0, 1)))
             if good:
                 torch.distributed.barrier()
                 w0 = time.perf_counter()
@@ -675,28 +675,20 @@ def main():
     # ---- N>1: the launch schedule of a step is chosen by measurement (the reference's auto-tuner does the same with its block
     # sizes before the trials, yask_main.cpp:334-335): which of "hide the exchange behind a split interior" and "one full-speed
     # launch, then the exchange" wins depends on link speed vs the cost of cutting the box
-    # "planned" / "planned35": the rank box as ONE launch of equal blocks in rounds, shell blocks first, the exchange released from the
-    # device when they are done (round 3; the shell is to be done after 55 / 35 % of the launch: earlier = more rounds = more chunk
-    # prologues); "slabs": round 2's exterior slabs, then the interior; "serial": the whole box, then the exchange
-    # "halves" (late round 3): two launches in regular order -- the outer and the inner half of the x range -- each followed by the
-    # exchange of its own part of the faces, which travels while the other half is computed (no shell-first order; where a rank's box
-    # does not allow it the library falls back to "planned")
-    SCHEDULES = {"planned": "-overlap_comms -hip_planned_launch -no-hip_halves -hip_shell_pct 55 -no-hip_inline_pack",
-                 "planned35": "-overlap_comms -hip_planned_launch -no-hip_halves -hip_shell_pct 35 -no-hip_inline_pack",
-                 # (the halos packed between the two parts of the launch, on the compute stream, instead of beside the second part)
-                 "planned_inlinepack": "-overlap_comms -hip_planned_launch -no-hip_halves -hip_shell_pct 55 -hip_inline_pack",
-                 "halves": "-overlap_comms -hip_planned_launch -hip_halves -hip_shell_pct 55 -no-hip_inline_pack",
-                 "slabs": "-overlap_comms -no-hip_planned_launch -no-hip_halves -hip_overlap_splits 1", "serial": "-no-overlap_comms -no-hip_halves"}
+    # "halves": two launches in regular order -- the outer and the inner half of the x range -- each followed by the exchange of its own
+    # part of the faces, which travels while the other half is computed (the library's default since round 5; where a rank's box does
+    # not allow it the library falls back to "planned"); "planned": ONE plan of equal blocks in rounds, shell blocks first, the exchange
+    # released by an event behind the shell's rounds; "slabs": exterior slabs, then the interior; "serial": the whole box, then the exchange
+    SCHEDULES = {"halves": "-overlap_comms -hip_planned_launch -hip_halves", "planned": "-overlap_comms -hip_planned_launch -no-hip_halves",
+                 "slabs": "-overlap_comms -no-hip_planned_launch -no-hip_halves", "serial": "-no-overlap_comms -no-hip_halves"}
     AUTO_SCHEDULES = ("planned", "halves", "serial")
     schedule, schedule_ms = None, None
     t = 0
     if world > 1:
-        schedule = "planned" if args.schedule == "auto" else args.schedule
+        schedule = "halves" if args.schedule == "auto" else args.schedule
         if args.schedule == "auto":
             schedule_ms = {}
-            # (round 4: three candidates -- the exchange after the launch, and the two overlapping schedules; planned35 /
-            #  planned_inlinepack / slabs differ from these by less than the placement lottery on the one-GPU instruments and stay
-            #  selectable with --schedule)
+            # (three candidates: the exchange after the launch, and the two overlapping schedules; slabs stays selectable)
             def trial(fn):
                 """run fn on this rank; True only if it worked on EVERY rank (the same collectives are issued either way)"""
                 ok = 1

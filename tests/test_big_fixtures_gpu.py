@@ -14,7 +14,7 @@ from test_decomposed_blocks_gpu import G, INDEX, _run_ranks
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("opts", ["", "-hip_halves"])
+@pytest.mark.parametrize("opts", ["", "-no-hip_halves"])
 def test_iso3dfd_config4_global_grid_over_eight_ranks_matches_the_reference(gpu, opts):
     """BASELINE.json configs[3] itself: iso3dfd on the GLOBAL grid 2048 x 2048 x 1024, cut 2x2x2 into eight 1024 x 1024 x 512 blocks
     (here: eight processes on one GPU, IPC transport, default options / the halves schedule), against what the UNMODIFIED reference

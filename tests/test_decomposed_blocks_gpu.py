@@ -172,12 +172,12 @@ def _check_against_one_rank_and_reference(parts, one, stencil, g, steps, stride,
 
 @pytest.mark.parametrize("world,nr,transport,opts", [
     (2, (1, 1, 2), "ipc", ""),                                                 # two 1024 x 1024 x 512 blocks (config 4's block), z face
-    (8, (2, 2, 2), "ipc", ""),                                                 # eight 512^3 blocks, three faces each, planned launches
-    (8, (2, 2, 2), "ipc", "-hip_halves"),                                      # ... as two launches per step with pipelined half-exchanges
-    # round 2's slabs + interior in two launches: differed from the one-rank run in the last bit of ~0.2 % of the points per step
+    (8, (2, 2, 2), "ipc", "-no-hip_halves"),                                   # eight 512^3 blocks, three faces each, planned launches
+    (8, (2, 2, 2), "ipc", ""),                                                 # ... as two launches per step with pipelined half-exchanges (default)
+    # round 2's slabs + interior (then in two launches): differed from the one-rank run in the last bit of ~0.2 % of the points per step
     # until the partial sums were written as explicit FMAs (ykh_device.hpp fmacc: the compiler fused `c*c0 + p*c1` differently in the
     # even and the odd plane copies of a trip, so the last bit depended on the parity of the x-chunk start; profiles/r3_bitexact)
-    (8, (2, 2, 2), "tcp", "-no-hip_planned_launch -no-hip_thin_slab_point_kernel -hip_overlap_splits 2"),
+    (8, (2, 2, 2), "tcp", "-no-hip_planned_launch -no-hip_thin_slab_point_kernel"),
 ])
 def test_iso3dfd_1024_cut_over_ranks_equals_one_rank_and_the_reference(gpu, world, nr, transport, opts):
     meta = INDEX["c2_iso3dfd_1024_s2_lattice"]

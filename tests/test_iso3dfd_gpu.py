@@ -179,12 +179,11 @@ def test_full_size_1024_properties(gpu):
     a.end_solution()
 
 
-@pytest.mark.parametrize("opt", ["-hip_round_launches", "-no-hip_round_launches"])
-def test_more_tiles_than_cus(gpu, opt):
-    """A plane of 9 x 32 = 288 tiles on 256 CUs: by default the tile rows are launched one CU-filling round at a
-    time (-hip_round_launches); either way the result equals the point kernel's."""
+def test_more_tiles_than_cus(gpu):
+    """A plane of 9 x 32 = 288 tiles on 256 CUs: the tile rows are launched one CU-filling round at a time; the result equals the
+    point kernel's."""
     size, steps = (12, 1024, 1100), 2
-    _, _, a = make(size, opt)
+    _, _, a = make(size, "")
     assert a.get_kernel_variant(0).startswith("starlin")
     _, _, b = make(size, "-force_scalar")
     a.run_solution(0, steps - 1)

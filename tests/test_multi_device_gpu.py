@@ -32,7 +32,7 @@ FIELDS = {"iso3dfd": ["p"], "ssg": O.SSG_FIELDS}
 # one kernel everywhere (bit-exactness vs one rank): the shapes the library picks for large boxes, named
 KERNEL = {"iso3dfd": "-hip_variant starlin_v4_z128_y16_r1_m_nt_w2_c4 -no-hip_thin_slab_point_kernel",
           "ssg": "-hip_variant march_v2_z128_y8_w2 -no-hip_thin_slab_point_kernel"}
-SCHEDULES = {"serial": "-no-overlap_comms", "planned": "-overlap_comms -hip_planned_launch", "halves": "-overlap_comms -hip_halves"}
+SCHEDULES = {"serial": "-no-overlap_comms", "planned": "-overlap_comms -hip_planned_launch -no-hip_halves", "halves": "-overlap_comms -hip_halves"}
 WATCHDOG_S = 90
 
 

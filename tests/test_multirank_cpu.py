@@ -641,8 +641,7 @@ def _plan(n, lo, hi, width=(8, 8, 8), ty=32, tz=128, overhead=9, ncu=256, shell_
 @pytest.mark.parametrize("n,lo,hi,ty,tz", [((40, 44, 72), (0, 0, 0), (1, 1, 1), 16, 32), ((64, 30, 50), (1, 1, 1), (1, 1, 1), 8, 16),
                                            ((33, 17, 129), (1, 0, 0), (0, 0, 1), 32, 128), ((48, 48, 48), (0, 0, 0), (0, 0, 0), 16, 16),
                                            ((24, 64, 64), (0, 1, 0), (0, 0, 0), 16, 64), ((20, 10, 200), (1, 0, 1), (1, 0, 0), 4, 64)])
-@pytest.mark.parametrize("mode", [0, 1, 2])
-def test_block_plan_covers_the_rank_box_exactly_once_shell_first(n, lo, hi, ty, tz, mode):
+def test_block_plan_covers_the_rank_box_exactly_once_shell_first(n, lo, hi, ty, tz, mode=0):
     """Solution::launch_planned() hands workgroup i the i-th descriptor of yk_plan_blocks().  Whatever the plan, every point of
     the rank box must be computed exactly once, every block must be ONE tile of the regular (ty, tz) tiling (the kernel's
     threads cover exactly that), the shell -- every point a neighbour needs: within `width` of a face that has one -- must be
@@ -766,3 +765,13 @@ def test_halves_cut_a_face_at_the_same_planes_on_both_sides_and_x_faces_travel_f
     a, b = _capi.idx_t(), _capi.idx_t()
     assert _lib().yk_plan_halves(24, 8, C.byref(a), C.byref(b)) == 0
     assert _lib().yk_plan_halves(32, 8, C.byref(a), C.byref(b)) == 1 and (a.value, b.value) == (8, 24)
+
+
+def test_block_plan_refuses_the_deleted_planner_modes():
+    """round 5: modes 1 / 2 (thin x slabs with per-CU budgets / uniform interior chunks, measured 1.3-1.6x) are gone"""
+    A3, I3 = _capi.idx_t * 3, C.c_int * 3
+    for mode in (1, 2, 7):
+        info = (_capi.idx_t * 5)()
+        assert _lib().yk_plan_blocks(A3(40, 44, 72), I3(0, 0, 0), I3(1, 1, 1), A3(8, 8, 8), 32, 128, 9, 256, 55, mode, None, 0, info) < 0
+        assert b"mode must be 0" in _lib().yk_last_error()
+        _lib().yk_clear_error()

@@ -6,7 +6,7 @@ one step, with no communication, and compares with the undivided box (yk_solutio
   * planned launches (round 3, the default): ONE launch of the marching kernel over the rank box, shell blocks first; `shell_ms`
     = until the device-side signal that releases the halo exchange, `rest_ms` = from there to the end of the launch;
   * round 2's separate launches (-no-hip_planned_launch): exterior slabs (thin ones on the point kernel, the z exterior one
-    marching tile wide), then the interior in -hip_overlap_splits pieces.
+    marching tile wide), then the interior.
     python tools/decomp_cost.py [--stencil iso3dfd] [--quick]"""
 import argparse
 import json
@@ -27,18 +27,11 @@ SSG_CASES = [
     ("ssg 1024^3 global / 8 GPUs, 2x2x2, local 512^3", (512, 512, 512), (0, 0, 0), (1, 1, 1)),
 ]
 CONFIGS = [  # label, options
-    # round 3, late: the pipelined half-exchange schedule -- outer x-half, inner x-half, regular order (shell_ms = the outer half)
-    ("halves: two launches in regular order (-hip_halves)", "-hip_planned_launch -hip_halves"),
-    ("planned rounds pct55 (default)", "-no-hip_halves -hip_planned_launch -hip_shell_pct 55 -hip_plan_mode 0"),
-    ("planned rounds pct35", "-no-hip_halves -hip_planned_launch -hip_shell_pct 35 -hip_plan_mode 0"),
-    ("planned, one round if shortest (pct100: descriptors + signals, no early shell)", "-no-hip_halves -hip_planned_launch -hip_shell_pct 100 -hip_plan_mode 0"),
-    ("planned rounds pct55, blocks in regular-launch order (shell not first)", "-no-hip_halves -hip_planned_launch -hip_shell_pct 55 -hip_plan_mode 3"),
-    ("first planner: thin x slabs + per-CU budgets", "-no-hip_halves -hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 1"),
-    ("first planner: uniform interior chunks", "-no-hip_halves -hip_planned_launch -hip_shell_pct 45 -hip_plan_mode 2"),
-    ("slabs, interior in 2 launches (round 2 default)", "-no-hip_halves -no-hip_planned_launch -hip_overlap_splits 2"),
-    ("slabs, interior in 1 launch", "-no-hip_halves -no-hip_planned_launch -hip_overlap_splits 1"),
-    # compute side of the multi-rank wave-front tiling: one step's share of a 2-step group on extended, shrinking boxes
-    ("wave-front tiling across ranks, -Mbt 2 (per step)", "-Mbt 2 -hip_wf_ext_always"),
+    # the schedules the library compiles since round 5 (the first planner, shell percentages, in-line pack, the one-launch / device-signal
+    # form, split interiors and side-by-side slabs of rounds 2-3 were measured here -- profiles/r3_decomp, r3_halves -- and are deleted)
+    ("halves: two launches in regular order (default)", "-hip_planned_launch -hip_halves"),
+    ("planned: one plan of equal blocks, shell first (-no-hip_halves)", "-no-hip_halves -hip_planned_launch"),
+    ("slabs + interior (-no-hip_planned_launch)", "-no-hip_halves -no-hip_planned_launch"),
 ]
 
 
@@ -85,10 +78,10 @@ def main():
     # Every schedule option is a run-time toggle (plans are rebuilt, nothing is re-allocated), so by default ALL configurations of a
     # case are timed on ONE solution, i.e. on one set of var allocations, in --passes interleaved passes: where the arrays happen to
     # lie is worth 3-4 % of a step -- more than what some of these schedules differ by (profiles/r3_halves: the
-    # "undivided" column of one case read 0.403 / 0.431 / 0.439 ms on three solutions).  Configurations that change the allocation
-    # (-Mbt with -hip_wf_ext_always) get their own solution; --fresh-solutions restores one solution per configuration.
+    # "undivided" column of one case read 0.403 / 0.431 / 0.439 ms on three solutions).  --fresh-solutions restores one solution per
+    # configuration.
     def own_solution(opts):
-        return args.fresh_solutions or "-Mbt" in opts or "-hip_wf_ext_always" in opts
+        return args.fresh_solutions
 
     for name, size, lo, hi in cases:
         shared = None

@@ -39,11 +39,11 @@ def main():
     import multiprocessing as mp
     a, ka = D.run_one("")
     print("one rank default kernel", ka, flush=True)
-    for o in ("-hip_xchunk 256", "-hip_xchunk 103", "-hip_xchunk 256 -no-hip_round_launches"):
+    for o in ("-hip_xchunk 256", "-hip_xchunk 103"):
         b, _ = D.run_one(o)
         hist(f"one rank '{o}'", a, b)
-    L = "-no-hip_planned_launch -no-hip_thin_slab_point_kernel -hip_overlap_splits 2"
-    for opts in (L, L + " -hip_xchunk 512", L + " -hip_xchunk 256", L + " -hip_xchunk 128", L + " -hip_xchunk 103", L + " -hip_xchunk 512 -no-hip_round_launches"):
+    L = "-no-hip_planned_launch -no-hip_thin_slab_point_kernel"
+    for opts in (L, L + " -hip_xchunk 512", L + " -hip_xchunk 256", L + " -hip_xchunk 128", L + " -hip_xchunk 103"):
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()

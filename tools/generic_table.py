@@ -69,6 +69,10 @@ def run_one(stencil, sizes, steps, opts=""):
         parts.append({"part": p, "name": pi["name"], "stage": pi["stage"], "scratch": bool(pi["is_scratch"]), "condition": bool(pi["has_condition"]),
                       "kernel": var, "family": family(var), "points": pi["points"], "arrays_read": pi["arrays_read"], "arrays_written": pi["arrays_written"],
                       "scratch_arrays": pi["scratch_arrays_read"] + pi["scratch_arrays_written"], "fp_ops_per_point": pi["fp_ops"],
+                      "reads_per_point": pi["points_read"], "writes_per_point": pi["points_written"],
+                      # what the loads of the part would move if none were shared between lanes or kept in registers: the rate the
+                      # L1 / LDS side sees (against ~64 B/clk/CU = 35-39 TB/s of vector-L1 bandwidth)
+                      "load_rate_tbs": round(pi["points"] * pi["points_read"] * eb / (pms * 1e-3) / 1e12, 2) if pms and pms > 0 else None,
                       "bytes_per_point": pi["compulsory_bytes_per_point"], "ms": round(pms, 4) if pms else None,
                       "compulsory_gbs": round(gbs, 1) if gbs else None, "frac": round(gbs / HBM_PEAK_GBS, 4) if gbs else None})
     rec = {"stencil": stencil, "size": list(size), "elem_bytes": eb, "steps": len(ms), "step_ms": round(step_ms, 4),
@@ -99,7 +103,9 @@ def markdown(recs, title):
         worst = min(timed, key=lambda p: p["frac"]) if timed else None
         out.append(f"| {r['stencil']} | {'x'.join(str(n) for n in r['size'])} | {len(r['parts'])} | {r['step_ms']} | {r['gpoints_per_s']} | {r['compulsory_gbs']} | "
                    f"**{r['frac']}** | {', '.join(f'{k} x{v}' if v > 1 else k for k, v in sorted(fams.items()))} | "
-                   + (f"{worst['part']} `{worst['name']}` on `{worst['kernel']}` ({worst['frac']})" if worst else "") + " |")
+                   + (f"{worst['part']} `{worst['name']}` on `{worst['kernel']}` ({worst['frac']}; {worst.get('reads_per_point', '?')} reads + "
+                      f"{worst.get('writes_per_point', '?')} writes per point over {worst['arrays_read']} + {worst['arrays_written']} arrays, "
+                      f"{worst['fp_ops_per_point']} flops, loads at {worst.get('load_rate_tbs', '?')} TB/s)" if worst else "") + " |")
     return "\n".join(out) + "\n"
 
 

@@ -37,9 +37,6 @@ GRID_CASES = [("c2 1024^3 / 2x2x2: 512^3 block", (1024, 1024, 1024), (2, 2, 2), 
               ("c4 2048x2048x1024 / 8x1x1: 256x2048x1024 block", (2048, 2048, 1024), (8, 1, 1), 1)]
 SCHEDULES = [("halves: two launches in regular order, half-exchanges pipelined (-hip_halves)", "-overlap_comms -hip_planned_launch -hip_halves"),
              ("planned (rounds, shell first)", "-overlap_comms -hip_planned_launch -no-hip_halves"),
-             ("planned, pack in line on the compute stream (-hip_inline_pack)", "-overlap_comms -hip_planned_launch -no-hip_halves -hip_inline_pack"),
-             ("planned, one launch + device-side signal (-no-hip_planned_split)", "-overlap_comms -hip_planned_launch -no-hip_halves -no-hip_planned_split"),
-             ("planned, shell by 35 %", "-overlap_comms -hip_planned_launch -no-hip_halves -hip_shell_pct 35"),
              ("slabs + interior (round 2)", "-overlap_comms -no-hip_planned_launch -no-hip_halves"),
              ("whole box, then exchange", "-no-overlap_comms")]
 
@@ -78,7 +75,7 @@ def main():
         # Every schedule is a set of run-time options, so by default all schedules of a case run on ONE env + solution, i.e. on one
         # set of var allocations, in --passes interleaved passes (where the arrays lie is worth 3-4 % of a step, DESIGN.md section 2:
         # more than some schedules differ by); --fresh-solutions = one solution per schedule, as before the end of round 3.
-        RESET = "-overlap_comms -hip_planned_launch -no-hip_halves -no-hip_inline_pack -hip_planned_split -hip_shell_pct 55 "
+        RESET = "-overlap_comms -hip_planned_launch -no-hip_halves "
 
         def make(opts):
             env = fac.new_env()

@@ -9,6 +9,13 @@ void s3axis_variants_k2(PartImpl& p) {
     p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_MOVE, 1 | 2, 2, 4>());
     p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_MOVE, 1 | 4, 2, 4>());
 #endif
+#ifdef YKH_PROFILING      // round 5 A/B: soft lock-step of an XCD's workgroups every 1 / 2 / 4 / 8 / 16 planes (profiles/r5_3axis_lockstep)
+    p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_MOVE, 1 | (1 << 8), 2, 4>());
+    p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_MOVE, 1 | (2 << 8), 2, 4>());
+    p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_MOVE, 1 | (3 << 8), 2, 4>());
+    p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_MOVE, 1 | (4 << 8), 2, 4>());
+    p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_MOVE, 1 | (5 << 8), 2, 4>());
+#endif
 #ifdef YKH_PROFILING      // write-through output stores: measured 1-12 % slower, profiles/r4_wt
     p.variants.push_back(starlin_variant<part_1, 2, 64, 8, 4, ROT_MOVE, 1 | 128, 2, 4>());
 #endif

@@ -81,10 +81,10 @@ yk_soln_h yk_new_solution_from(yk_env_h env, yk_soln_h source) {
     d.auto_tune = o.auto_tune; d.force_scalar = o.force_scalar; d.variant_override = o.variant_override;
     d.xchunk_override = o.xchunk_override;
     // every cdna4_hip-specific setting as well: a validation copy must run the same configuration
-    d.direct_halo = o.direct_halo; d.overlap_splits = o.overlap_splits; d.round_launches = o.round_launches;
+    d.direct_halo = o.direct_halo; 
     d.thin_slab_point_kernel = o.thin_slab_point_kernel; d.tune_at_prepare = o.tune_at_prepare;
     d.auto_tune_trial_secs = o.auto_tune_trial_secs; d.step_wrap = o.step_wrap; d.step_timers = o.step_timers;
-    d.ignored_opts = o.ignored_opts; d.fuse_steps = o.fuse_steps; d.comm_cus = o.comm_cus; d.ext_streams_mode = o.ext_streams_mode; d.pitch_extra = o.pitch_extra; d.step_graphs = o.step_graphs; d.fast_div = o.fast_div; d.var_skew = o.var_skew; d.placement_trials = o.placement_trials;
+    d.ignored_opts = o.ignored_opts; d.fuse_steps = o.fuse_steps; d.step_graphs = o.step_graphs; d.fast_div = o.fast_div; d.placement_trials = o.placement_trials;
     return s;
     YK_CATCH(nullptr)
 }
@@ -266,7 +266,7 @@ yk_idx_t yk_solution_get_last_rank_domain_index(yk_soln_h s, const char* dim) {
 }
 int yk_solution_run(yk_soln_h s, yk_idx_t a, yk_idx_t b) { YK_TRY S(s).run(a, b); return 0; YK_CATCH(1) }
 int yk_solution_end(yk_soln_h s) { YK_TRY S(s).end(); return 0; YK_CATCH(1) }
-int yk_solution_exchange_halos(yk_soln_h s) { YK_TRY S(s).exchange_halos_all(); S(s).synchronize(); S(s).check_async_errors("exchange_halos()", false); return 0; YK_CATCH(1) }
+int yk_solution_exchange_halos(yk_soln_h s) { YK_TRY S(s).exchange_halos_all(); S(s).synchronize(); S(s).check_async_errors("exchange_halos()"); return 0; YK_CATCH(1) }
 int yk_solution_copy_vars_to_device(yk_soln_h s) { YK_TRY S(s).copy_vars_to_device(); return 0; YK_CATCH(1) }
 int yk_solution_copy_vars_from_device(yk_soln_h s) { YK_TRY S(s).copy_vars_from_device(); return 0; YK_CATCH(1) }
 int yk_solution_get_stats(yk_soln_h s, yk_stats_t* out) {

@@ -194,26 +194,6 @@ void Solution::exchange_build_and_pack(hipStream_t st) {
     launch_halo_move(segs, /*pack=*/true, elem_bytes(), st);
 }
 
-// Planned launch in two parts (launch_planned, planned_split): called between them ON THE COMPUTE STREAM.  The second part's blocks
-// take every CU the moment the first part ends, and a pack kernel on the comm stream then finds no wave slot until they are done
-// (measured: its 0.02 ms became 0.21 ms, the whole second part, and the exchange was not hidden at all, tools/overlap_probe.py):
-// packing in line costs the launch those 0.02 ms and lets the transfer run beside the second part.  The send buffers are free:
-// the compute stream has waited for the previous exchange's unpack, which the comm stream ran behind its sends.
-void Solution::exchange_prepack(hipStream_t st) {
-    prepacked_ = false;
-    if (env->nranks <= 1 || xfers.empty() || !env->exch_start) return;
-    bool any = false;
-    for (auto& v : vars)
-        for (char d : v->dirty) any |= (d != 0);
-    pending_msgs.clear();
-    prepacked_ = true;
-    if (!any) return;
-    phase_mark(PH_EXT1, st);
-    phase_mark(PH_PACK0, st);
-    exchange_build_and_pack(st);
-    phase_mark(PH_PACK1, st);
-}
-
 // start_only : pack + begin transport on the comm stream (after everything queued on the compute stream);
 // finish_only: wait for arrival, unpack, and make the compute stream wait for the unpack.
 void Solution::exchange_halos(idx_t /*t_written*/, int /*stage*/, bool start_only, bool finish_only) {
@@ -221,14 +201,9 @@ void Solution::exchange_halos(idx_t /*t_written*/, int /*stage*/, bool start_onl
     if (!env->exch_start) YKH_THROW("multi-rank solution has no halo-exchange transport installed in its env");
     std::vector<HaloMsg>& msgs = pending_msgs;      // messages between a start and the matching finish
     if (!finish_only) {
-        const bool signalled = sig_pending, evented = shell_event_pending, prepacked = prepacked_;
-        sig_pending = shell_event_pending = prepacked_ = false;
-        if (prepacked) {
-            // (the messages were built and packed on the compute stream between the two parts of a planned launch; ev_shell was
-            //  recorded behind the pack)
-            if (msgs.empty()) return;
-            YKH_HIP(hipStreamWaitEvent(comm_stream, ev_shell, 0));
-        } else {
+        const bool evented = shell_event_pending;
+        shell_event_pending = false;
+        {
             bool any = false;
             for (auto& v : vars)
                 for (char d : v->dirty) any |= (d != 0);
@@ -238,13 +213,6 @@ void Solution::exchange_halos(idx_t /*t_written*/, int /*stage*/, bool start_onl
                 // planned launch in two parts: the comm stream waits for the event behind the shell's rounds
                 YKH_HIP(hipStreamWaitEvent(comm_stream, ev_shell, 0));
                 phase_mark(PH_EXT1, comm_stream);
-            } else if (signalled) {
-                // planned launch: the data the neighbours need comes from the launch's shell blocks, which publish an epoch when the
-                // last of them has finished (block_done(), ykh_device.hpp) -- the comm stream waits for THAT, not for the launch
-                const unsigned* wp = sig_dev + 1;
-                const unsigned wv = sig_epoch;
-                launch_wait_words(1, &wp, &wv, sig_dev + 2, 20.0, comm_stream);
-                phase_mark(PH_EXT1, comm_stream);         // = the exterior is done (interior_secs then runs from here to PH_INT1)
             } else {
                 // comm stream waits for the kernels that produced the data
                 YKH_HIP(hipEventRecord(ev_a, compute_stream));

@@ -224,7 +224,8 @@ std::vector<T> deal_over_xcds(const std::vector<T>& v) {
 }
 }  // namespace
 
-// Mode 0 ("rounds"), the default.  What the first planner (modes 1 / 2 below) got wrong, measured on the GPU (gpurun_out/r3a):
+// Mode 0 ("rounds").  What round 3's first planner (thin x slabs, greedy per-CU budgets or uniform interior chunks: deleted in round 5)
+// got wrong, measured on the GPU (gpurun_out/r3a, 1.3-1.6x):
 // pieces sized per CU start at different times and places, so the ~250 concurrent workgroups of a launch march through ~250
 // different x planes -- and the kernel runs 1.5x slower per plane than in a regular launch, where all tiles of a chunk sweep
 // the same planes at the same time (DRAM pages, TLB reach and the L2 sharing of halo lines all depend on it; round 2 had seen
@@ -436,133 +437,8 @@ BlockPlan plan_blocks(const BlockPlanIn& in) {
     const idx_t nx = in.n[0], ny = in.n[1], nz = in.n[2];
     if (nx < 1 || ny < 1 || nz < 1 || in.ty < 1 || in.tz < 1 || in.ncu < 1) throw PlanError("plan_blocks: bad box or tile");
     if (in.mode == 4) return plan_halves(in);
-    if (in.mode == 0 || in.mode == 3) return plan_rounds(in);
-    const idx_t o = std::max<idx_t>(0, in.overhead), minlen = std::max<idx_t>(1, in.min_len);
-    auto desc = [](const TileBox& tb, idx_t x0, idx_t x1, int flags, idx_t start) {
-        BlockDesc d;
-        d.x0 = (int)x0; d.x1 = (int)x1; d.y0 = (int)tb.y0; d.y1 = (int)tb.y1; d.z0 = (int)tb.z0; d.z1 = (int)tb.z1;
-        d.flags = flags; d.start = (int)start;
-        return d;
-    };
-    // ---- tiles of the regular tiling; shell tiles = those a y / z neighbour needs something of
-    std::vector<TileBox> shell_t, inner_t, all_t;
-    auto touches = [&](idx_t a, idx_t b, idx_t n, int d) {       // does [a, b) reach into the boundary strips of dim d?
-        const idx_t w = std::max<idx_t>(1, in.width[d]);
-        return (in.has_lo[d] && a < w) || (in.has_hi[d] && b > n - w);
-    };
-    for (idx_t y0 = 0; y0 < ny; y0 += in.ty)
-        for (idx_t z0 = 0; z0 < nz; z0 += in.tz) {
-            TileBox tb{y0, std::min(y0 + in.ty, ny), z0, std::min(z0 + in.tz, nz)};
-            all_t.push_back(tb);
-            (touches(tb.y0, tb.y1, ny, 1) || touches(tb.z0, tb.z1, nz, 2) ? shell_t : inner_t).push_back(tb);
-        }
-    // ---- x: thin shell slabs next to x neighbours, the main range between them
-    idx_t xa = 0, xb = nx;
-    const idx_t wx = std::max<idx_t>(1, in.width[0]);
-    if (in.has_lo[0]) xa = std::min(wx, nx);
-    if (in.has_hi[0]) xb = std::max(xa, nx - wx);
-    const idx_t nmain = xb - xa;
-    // ---- the undivided box as ONE regular launch, for reference: tiles x k uniform chunks, best k
-    {
-        idx_t best = -1;
-        for (idx_t k = 1; k <= 64; k++) {
-            const idx_t len = (nx + k - 1) / k;
-            if (k > 1 && len < 32) break;
-            CuLine cl(in.ncu);
-            for (idx_t c = 0; c * len < nx; c++)
-                for (size_t i = 0; i < all_t.size(); i++) cl.run(std::min(len, nx - c * len) + o);
-            if (best < 0 || cl.makespan() < best) best = cl.makespan();
-        }
-        out.undivided = best;
-    }
-    const bool any_nb = in.has_lo[0] || in.has_hi[0] || !shell_t.empty();
-    CuLine cl(in.ncu);
-    std::vector<BlockDesc> shell_blocks;
-    // 1. x-face slabs of every tile
-    if (in.has_lo[0] && xa > 0) for (auto& tb : all_t) shell_blocks.push_back(desc(tb, 0, xa, BLOCK_SIGNALS, cl.run(xa + o)));
-    if (in.has_hi[0] && xb < nx) for (auto& tb : all_t) shell_blocks.push_back(desc(tb, xb, nx, BLOCK_SIGNALS, cl.run(nx - xb + o)));
-    // 2. y/z shell tiles over the main x range, in chunks that end after ~shell_frac of the launch
-    const double work = (double)all_t.size() * (double)nx;                 // tile-planes
-    const idx_t t_est = (idx_t)(work / (double)in.ncu) + o;
-    if (nmain > 0 && !shell_t.empty()) {
-        idx_t ls = (idx_t)(in.shell_frac * (double)t_est) - o;
-        ls = std::max<idx_t>(std::max<idx_t>(minlen, 24), ls);
-        idx_t ks = std::max<idx_t>(1, (nmain + ls - 1) / ls);
-        // (more shell blocks than CUs would run in rounds and finish no earlier: cap the count at what is resident at a time)
-        while (ks > 1 && (idx_t)shell_t.size() * ks + (idx_t)shell_blocks.size() > in.ncu) ks--;
-        std::vector<BlockDesc> yz;
-        for (idx_t c = 0; c < ks; c++) {
-            const idx_t a = xa + nmain * c / ks, b = xa + nmain * (c + 1) / ks;
-            for (auto& tb : shell_t) yz.push_back(desc(tb, a, b, BLOCK_SIGNALS, 0));
-        }
-        for (auto& d : yz) { d.start = (int)cl.run((d.x1 - d.x0) + o); shell_blocks.push_back(d); }
-    }
-    out.shell_done = any_nb ? cl.makespan() : 0;
-    out.n_signal = (idx_t)shell_blocks.size();
-    // ---- 3. interior tiles over the main range
-    std::vector<BlockDesc> inner_blocks;
-    idx_t inner_makespan = cl.makespan();
-    if (nmain > 0 && !inner_t.empty()) {
-        // (a) greedy budgets: every CU, in the order in which it frees up, takes pieces of the (tile, x) space until time T
-        auto greedy = [&](idx_t T, std::vector<BlockDesc>* emit) -> bool {
-            std::vector<idx_t> av = cl.t;
-            std::vector<size_t> order(av.size());
-            for (size_t i = 0; i < order.size(); i++) order[i] = i;
-            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return av[a] < av[b]; });
-            size_t ti = 0;
-            idx_t x = xa;
-            for (size_t oi = 0; oi < order.size() && ti < inner_t.size(); oi++) {
-                idx_t tcu = av[order[oi]];
-                while (ti < inner_t.size()) {
-                    idx_t budget = T - tcu - o;
-                    const idx_t left = xb - x;
-                    if (budget < std::min(minlen, left)) break;
-                    idx_t len = std::min(budget, left);
-                    if (left - len < minlen) len = left;              // no sliver at the end of a tile
-                    if (emit) emit->push_back(desc(inner_t[ti], x, x + len, 0, tcu));
-                    tcu += len + o;
-                    x += len;
-                    if (x >= xb) { ti++; x = xa; }
-                }
-            }
-            return ti >= inner_t.size();
-        };
-        idx_t lo = 1, hi = 4 * (t_est + o) + nmain + cl.makespan();
-        while (lo < hi) { const idx_t mid = (lo + hi) / 2; if (greedy(mid, nullptr)) hi = mid; else lo = mid + 1; }
-        std::vector<BlockDesc> g;
-        greedy(lo, &g);
-        std::stable_sort(g.begin(), g.end(), [](const BlockDesc& a, const BlockDesc& b) { return a.start < b.start; });
-        idx_t g_span = 0;
-        {
-            CuLine c2 = cl;
-            for (auto& d : g) { const idx_t s = c2.run((d.x1 - d.x0) + o); (void)s; }
-            g_span = c2.makespan();
-        }
-        // (b) uniform chunks: every interior tile cut at the same planes (neighbouring tiles march in step and share their
-        // halo lines in L2), chunk count chosen by simulated makespan
-        std::vector<BlockDesc> u;
-        idx_t u_span = -1;
-        for (idx_t k = 1; k <= 64; k++) {
-            if (k > 1 && nmain / k < minlen) break;
-            CuLine c2 = cl;
-            std::vector<BlockDesc> cand;
-            for (idx_t c = 0; c < k; c++) {
-                const idx_t a = xa + nmain * c / k, b = xa + nmain * (c + 1) / k;
-                for (auto& tb : inner_t) cand.push_back(desc(tb, a, b, 0, c2.run((b - a) + o)));
-            }
-            if (u_span < 0 || c2.makespan() < u_span) { u_span = c2.makespan(); u.swap(cand); }
-        }
-        const bool use_g = in.mode == 1;
-        out.mode_used = use_g ? 1 : 2;
-        inner_blocks = use_g ? g : u;
-        inner_makespan = use_g ? g_span : u_span;
-    }
-    out.makespan = std::max(inner_makespan, cl.makespan());
-    // dispatch order: shell first (dealt over the XCD strips), then the interior in planned start order
-    shell_blocks = deal_over_xcds(shell_blocks);
-    out.blocks = shell_blocks;
-    out.blocks.insert(out.blocks.end(), inner_blocks.begin(), inner_blocks.end());
-    return out;
+    if (in.mode != 0 && in.mode != 3) throw PlanError("plan_blocks: mode must be 0 (rounds, shell first), 3 (the same blocks in regular order) or 4 (halves)");
+    return plan_rounds(in);
 }
 
 }  // namespace ykh

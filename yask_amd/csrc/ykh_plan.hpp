@@ -54,9 +54,7 @@ struct BlockPlanIn {
     idx_t overhead = 8;                                   // plane-iterations a block spends before its first output plane
     idx_t ncu = 256;                                      // workgroups resident at a time (one per CU)
     double shell_frac = 0.45;                             // aim: the shell is done after this fraction of the launch
-    int mode = 0;                                         // 0: rounds -- every tile cut at the same planes, equal blocks, shell blocks first
-                                                          // (default); 1: thin x slabs + shell chunks + greedy per-CU budgets; 2: the same
-                                                          // with uniform interior chunks (the first planner: measured 1.3-1.6x, kept for A/B);
+    int mode = 0;                                         // 0: rounds -- every tile cut at the same planes, equal blocks, shell blocks first;
                                                           // 3: the blocks of 0 in regular-launch order (diagnostic); 4: the two x-halves of the
                                                           // pipelined half-exchange schedule (plan_halves below; NOT a shell-first plan)
     idx_t min_len = 16;                                   // no block shorter than this (unless its whole range is)
@@ -66,7 +64,7 @@ struct BlockPlan {
     idx_t n_signal = 0;
     idx_t makespan = 0, shell_done = 0;  // simulated, in plane-iterations
     idx_t undivided = 0;                 // the same box as ONE regular launch (tiles x best uniform chunks), simulated the same way
-    int mode_used = 0;                   // 3 rounds, 1 greedy, 2 uniform, 4 halves
+    int mode_used = 0;                   // 3 rounds, 4 halves
     idx_t cut = 0;                       // mode 4: blocks [0, cut) are half A (the first launch), [cut, size) half B
 };
 BlockPlan plan_blocks(const BlockPlanIn& in);

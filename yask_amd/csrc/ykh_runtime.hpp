@@ -54,6 +54,7 @@ struct KernelVariant {
     void (*launch_desc)(const PartArgs& a, dim3 grid, hipStream_t s) = nullptr;
     const void* func_desc = nullptr;
     int xover = 0;                // plane-iterations of overhead per block (prologue; the planner's cost model)
+    bool lockstep = false;        // "_ls<K>" shapes (profiling builds): PartArgs::sig = 8 zeroed per-XCD counters, see starlin_kernel
 };
 // bytes of scratch (private segment) per thread of a variant's kernel; > 0 means hipcc spilled registers
 size_t variant_scratch_bytes(const KernelVariant& kv);
@@ -363,29 +364,14 @@ public:
     bool overlap_comms = true;
     bool step_wrap = false;        // set_step_wrap(): any step index is accepted and wrapped onto the slots
     idx_t min_exterior = 0;
-    bool round_launches = true;           // -[no-]hip_round_launches: one launch per CU-filling round of tile rows
     bool thin_slab_point_kernel = true;   // -[no-]hip_thin_slab_point_kernel: thin y/z exterior slabs use the point kernel
     bool direct_halo = true;       // -[no-]hip_direct_halo: in-place transfer of contiguous x-face halos
-    idx_t overlap_splits = 1;      // -hip_overlap_splits: interior launches per stage of the slab schedule (each split re-runs the
-                                   // 16-plane prologue: iso3dfd 512^3 interior 0.355 / 0.387 / 0.472 ms at 1 / 2 / 4).  1 since round 3:
-                                   // the splits were there to let RCCL's kernels in between launches, which the copy-based IPC
-                                   // transport does not need.  (At 1024^3 a run with 2 splits used to differ from the one-rank run in the
-                                   // last bit of ~0.2 % of the points per step: the parity of an x-chunk start selected a differently
-                                   // contracted first add of the partial sums; explicit FMAs since -- ykh_device.hpp fmacc -- and every
-                                   // split is bit-identical, tests/test_decomposed_blocks_gpu.py)
-    idx_t ext_streams_mode = 0;    // -hip_ext_streams: 0 = exterior slabs one after another on the compute stream (default); 1 = every
-                                   // slab on its own stream, side by side, the interior after them; 2 = the interior beside them as
-                                   // well (the exchange waits for the slabs only).  Measured on one GPU (profiles/r02r_ext_streams):
-                                   // the cross-stream dependencies cost more than the idle CUs of the thin slabs -- exterior of a 512^3
-                                   // block 0.19 ms serial, 0.22-0.29 ms side by side; ext + int 0.575 / 0.617 / 0.667 ms for 0 / 1 / 2
     idx_t placement_trials = 1;    // -hip_placement_trials <n>: sets of var allocations prepare_solution() draws and times (tune_placement());
                                    // 1 (default) = take the first allocation: the search runs real kernels, holds two sets of arrays for
                                    // a moment and costs ~1-2 s, so it is the caller's decision (bench.py and the harnesses ask for 6)
     std::vector<float> placement_ms;   // ms per step measured on each set drawn by the last prepare(), and the one kept
     int placement_chosen = 0;
     void tune_placement();
-    idx_t var_skew = 0;            // -hip_var_skew <n>: experiment, see Var::allocate()
-    idx_t pitch_extra = 0;         // -hip_pitch_extra <n>: n x 256 B added to the row pitch of every var (channel-skew experiments)
     bool fast_div = true;          // -[no-]hip_fast_div: shapes whose fp32 divisions are a * v_rcp_f32(b) (<= 1.5 ulp; ssg's defaults, see
                                    // MarchAcc) may be the default; off = the correctly rounded siblings (PartImpl::exact_div_variant)
     idx_t step_graphs = -1;        // -hip_step_graphs: 1 = single-rank runs of several steps are captured once into a hipGraph (the
@@ -463,45 +449,22 @@ public:
     StepGraph* get_step_graph(idx_t t, idx_t dir, idx_t steps);
     Box interior_for(const bool* has_lo, const bool* has_hi) const;
     void launch_exterior(const StageMeta& sm, idx_t t, const Box& ib);
-    // exterior slabs side by side on ext_streams (after everything queued on the compute stream); returns the number of slabs,
-    // whose completion events are ext_events[0..n)
-    int launch_exterior_concurrent(const StageMeta& sm, idx_t t, const Box& ib);
-    int exterior_mode(const StageMeta& sm) const;      // ext_streams_mode, 0 for stages with scratch parts
-    std::vector<hipStream_t> ext_streams;
-    std::vector<hipEvent_t> ext_events;
-    hipEvent_t ev_stage = nullptr;
     void launch_interior(const StageMeta& sm, idx_t t, const Box& ib);
     // ---- planned launches of a decomposed rank: the whole rank box as ONE launch of the marching kernel, shell blocks first,
     // the halo exchange released from the device when the shell is done (ykh_plan.cpp plan_blocks; replaces exterior slabs +
     // interior pieces wherever the stage's kernel takes block descriptors)
     bool planned_launch = true;        // -[no-]hip_planned_launch
-    idx_t shell_pct = 55;              // -hip_shell_pct <n>: the shell should be done after n % of the launch (55: two rounds of equal
-                                       // blocks, the shell in the first; lower = more rounds = more chunk prologues)
-    idx_t plan_mode = 0;               // -hip_plan_mode <0|1|2>: 0 rounds of equal blocks (default); 1 / 2 the first planner (A/B only)
     struct LaunchPlan { std::string key; BlockPlan plan; BlockDesc* dev = nullptr; size_t cut = 0; };      // cut: end of the round that holds the last shell block
     std::vector<std::unique_ptr<LaunchPlan>> launch_plans;
-    unsigned* sig_dev = nullptr;       // [0] finished signalling blocks, [1] published epoch, [2] a waiter gave up (error), [3] unused
-    unsigned sig_count = 0, sig_epoch = 0;
-    bool sig_pending = false;          // the launch just issued publishes sig_epoch: exchange_halos() waits for it on the comm stream
-    bool sig_used = false;             // some launch of this run() signalled: run() checks the error word at the end
-    // -[no-]hip_planned_split (default on): the planned launch goes out as TWO launches, cut at the end of the round that holds the last
-    // shell block, with an event between them that releases the exchange -- no wave polling a word.  The one-wave waiter of the
-    // one-launch form takes a wave slot on some CU, and a marching block needs ALL registers of a CU (8 waves x 256 VGPRs): with
-    // the waiter resident the launch has 255 CUs, the 256th block of a round runs alone afterwards (+0.1 ms on a 0.46 ms launch,
-    // measured: tools/overlap_probe.py, profiles/r3_overlap).
-    bool planned_split = true;
+    unsigned* lockstep_dev = nullptr;  // per-XCD arrival counters of the "_ls" experiment shapes (8 x 32 words)
     bool shell_event_pending = false;  // ev_shell was recorded behind the shell part of the launch just issued
     hipEvent_t ev_shell = nullptr;
-    bool inline_pack = false;          // -[no-]hip_inline_pack: pack the halos between the two parts, on the compute stream (exchange_prepack);
-                                       // off since the pack kernel fits in the 16 VGPRs a marching twin leaves and runs beside the second part
-    bool prepacked_ = false;           // exchange_prepack() built and packed the messages of the exchange about to start
     void exchange_build_and_pack(hipStream_t st);
-    void exchange_prepack(hipStream_t st);
     int planned_part(const StageMeta& sm) const;        // the stage's one part if it can run as a planned launch, else -1
     int planned_variant_of(int part) const;             // the kernel shape whose descriptor-reading twin runs the part's planned launches, or -1
     mutable std::vector<int> planned_cache_;             // ... remembered per part (-2: not looked up yet); cleared with the launch plans
-    LaunchPlan* get_launch_plan(int part, const bool* has_lo, const bool* has_hi, bool wide_shell = false, int mode = -1);   // mode < 0: plan_mode
-    void launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hipStream_t s, bool inline_pack = false);
+    LaunchPlan* get_launch_plan(int part, const bool* has_lo, const bool* has_hi, bool wide_shell = false, int mode = -1);   // mode < 0: 0
+    void launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hipStream_t s);
     // ---- pipelined half-exchanges (-[no-]hip_halves): a stage of a decomposed rank is TWO launches in regular
     // order, the outer x-half A = [0, q1) u [q2, nx) and the inner half B = [q1, q2) (plan mode 4), each followed by the exchange of
     // its own part of the faces.  The exchange started behind one half is finished -- unpacked, the compute stream made to wait for
@@ -510,7 +473,8 @@ public:
     // Legal when what a half reads of a neighbour's data lies in the planes of that half: every written var is read face-only
     // (l1_norm <= 1; iso3dfd, 3axis, ssg), every stage one planned part, no wave-front extension; agreed across ranks in prepare().
     struct PhaseEvents;
-    bool halves = false;               // the option (off by default: round 3 ended before it was measured on a GPU)
+    bool halves = true;                // -[no-]hip_halves (default since round 5: regular launch order costs 1.01-1.02x the undivided sweep where the
+                                       // shell-first plan costs 1.05-1.12x, and every transfer has a whole launch to hide behind)
     bool halves_geom_ok_ = false;      // prepare(): legal here AND on every other rank
     idx_t halves_q1_ = 0, halves_q2_ = 0;
     int exch_half_ = -1;               // which slab lists exchange_halos() works on: -1 whole faces, 0 / 1 the halves
@@ -533,7 +497,7 @@ public:
     void run_fused(idx_t t0, idx_t npairs, idx_t dir);
     void launch_fused(idx_t t, const void* src, void* slot_b, void* dst, bool store_b);
     void exchange_halos_all();
-    void check_async_errors(const char* who, bool sig_used);      // after the streams have drained
+    void check_async_errors(const char* who);      // after the streams have drained
     Stats get_stats();       // returns and clears, like soln_apis.cpp:349-562
     void reset_auto_tuner(bool enable);
     void run_auto_tuner_now();
@@ -546,8 +510,6 @@ public:
     // internals used by ykh_halo.cpp / tuner
     void setup_rank();
     void launch_part(int part, idx_t t, const Box& box, hipStream_t s);
-    idx_t comm_cus = 0;                   // -hip_comm_cus: CUs the interior launches leave free while halos travel (RCCL's
-                                          // send/recv kernels need CUs; a marching launch otherwise holds one workgroup on every CU)
     bool launching_interior = false;      // set by launch_interior() of an overlapped exchange
     bool launching_exterior = false;      // set by run() around the exterior slabs of a decomposed run (thin-slab kernel choice)
     void launch_part_variant(int part, int variant, idx_t xchunk, idx_t t, const Box& box_in, hipStream_t s);
@@ -588,7 +550,6 @@ public:
     idx_t wf_angle_[MAX_DOMAIN_DIMS] = {0, 0, 0};     // widest halo per dim = the shift per phase
     idx_t wf_ext_[MAX_DOMAIN_DIMS] = {0, 0, 0};       // extra halo / pad per dim (0: plain sweeps)
     idx_t wf_ext(int d) const { return wf_ext_[d]; }
-    bool wf_ext_always = false;                        // -[no-]hip_wf_ext_always: allocate the extensions on one rank too (tools/decomp_cost.py)
     bool wf_multi() const { return wf_ext_[0] + wf_ext_[1] + wf_ext_[2] > 0; }
     void run_wavefront_multi(idx_t t0, idx_t nsteps, idx_t dir, const bool* has_lo, const bool* has_hi, bool exchange);
 };

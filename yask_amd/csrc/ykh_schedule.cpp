@@ -48,58 +48,12 @@ void Solution::launch_exterior(const StageMeta& sm, idx_t t, const Box& ib) {
         }
     }
 }
-// ... then the interior, while the halos travel.  The marching kernels keep one workgroup per CU resident for a whole
-// launch, so a single interior launch would leave no CU for the comm stream until it ends: the interior is split along x
-// into a few back-to-back launches; at each boundary CUs drain and the (higher priority) pack / send-recv / unpack
-// kernels get in.
-// The slabs of one stage are independent boxes (disjoint writes, reads of the previous stage's data only): each goes to its
-// own high-priority stream, ordered after everything queued on the compute stream so far (-hip_ext_streams 1 / 2).  Not the
-// default: on one GPU the cross-stream dependencies cost more than the idle CUs of thin slabs (ykh_runtime.hpp).
-int Solution::launch_exterior_concurrent(const StageMeta& sm, idx_t t, const Box& ib) {
-    if (!ev_stage) YKH_HIP(hipEventCreateWithFlags(&ev_stage, hipEventDisableTiming));
-    YKH_HIP(hipEventRecord(ev_stage, compute_stream));
-    int n = 0;
-    auto slab = [&](const Box& sb) {
-        if ((int)ext_streams.size() <= n) {
-            int lo = 0, hi = 0;
-            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
-            hipStream_t st = nullptr;
-            if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) != hipSuccess) YKH_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            ext_streams.push_back(st);
-            hipEvent_t e = nullptr;
-            YKH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ext_events.push_back(e);
-        }
-        YKH_HIP(hipStreamWaitEvent(ext_streams[n], ev_stage, 0));
-        for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, sb, ext_streams[n]);
-        YKH_HIP(hipEventRecord(ext_events[n], ext_streams[n]));
-        n++;
-    };
-    ScopedSet<bool> ext(launching_exterior, true);
-    Box rem = rank_box();
-    for (int d = 0; d < ndd; d++) {
-        if (ib.lo[d] > rem.lo[d]) { Box s = rem; s.hi[d] = ib.lo[d]; slab(s); rem.lo[d] = ib.lo[d]; }
-        if (ib.hi[d] < rem.hi[d]) { Box s = rem; s.lo[d] = ib.hi[d]; slab(s); rem.hi[d] = ib.hi[d]; }
-    }
-    return n;
-}
-// (parts that fill scratch vars share those arrays between the slabs: such stages keep the serial order)
-int Solution::exterior_mode(const StageMeta& sm) const {
-    for (int k = 0; k < sm.n_parts; k++)
-        if (impl.parts[sm.parts[k]].meta->is_scratch) return 0;
-    return has_outer ? 0 : (int)ext_streams_mode;
-}
-
+// ... then the interior, while the halos travel: ONE launch (round 2 split it along x to let RCCL's kernels in at the boundaries,
+// each split re-running the prologue: iso3dfd 512^3 interior 0.355 / 0.387 / 0.472 ms at 1 / 2 / 4 splits; the copy-based
+// transport needs no CU, and the schedules that overlap by construction -- halves, planned -- replaced the idea).
 void Solution::launch_interior(const StageMeta& sm, idx_t t, const Box& ib) {
-    const idx_t nxi = ib.hi[0] - ib.lo[0];
-    const idx_t nsplit = std::max<idx_t>(1, std::min<idx_t>(overlap_splits, nxi / 64));
     ScopedSet<bool> inter(launching_interior, true);
-    for (idx_t c = 0; c < nsplit; c++) {
-        Box b = ib;
-        b.lo[0] = ib.lo[0] + nxi * c / nsplit;
-        b.hi[0] = ib.lo[0] + nxi * (c + 1) / nsplit;
-        for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, b, compute_stream);
-    }
+    for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, ib, compute_stream);
 }
 // What the compute side of one step costs a rank with neighbours on the given sides -- the same launches run() issues,
 // without any communication -- against the undivided box.  tools/decomp_cost.py; ms[0] = exterior, ms[1] = interior,
@@ -111,36 +65,13 @@ void Solution::time_decomposed_step(const bool* has_lo, const bool* has_hi, int 
     hipEvent_t e[4];
     for (auto& x : e) YKH_HIP(hipEventCreate(&x));
     float acc[3] = {0, 0, 0};
-    const idx_t wf_steps = std::max<idx_t>(mega_block_size[0], block_size[0]);
-    if (wf_steps > 1 && wf_multi()) {
-        // wave-front tiling across ranks: ms[1] = one step's share of a group's launches (extended, shrinking boxes; no exchange),
-        // ms[2] = one plain sweep of the rank box, ms[0] = 0
-        for (int r = -1; r < reps; r++) {
-            YKH_HIP(hipEventRecord(e[0], compute_stream));
-            run_wavefront_multi((idx_t)(r + 1) * wf_steps, wf_steps, 1, has_lo, has_hi, /*exchange=*/false);
-            YKH_HIP(hipEventRecord(e[2], compute_stream));
-            for (idx_t k = 0; k < wf_steps; k++)
-                for (int st = 0; st < meta->n_stages; st++)
-                    for (int q = 0; q < meta->stages[st].n_parts; q++) launch_part(meta->stages[st].parts[q], r + 1, rb, compute_stream);
-            YKH_HIP(hipEventRecord(e[3], compute_stream));
-            YKH_HIP(hipEventSynchronize(e[3]));
-            if (r < 0) continue;
-            float m = 0;
-            YKH_HIP(hipEventElapsedTime(&m, e[0], e[2])); acc[1] += m / (float)wf_steps;
-            YKH_HIP(hipEventElapsedTime(&m, e[2], e[3])); acc[2] += m / (float)wf_steps;
-        }
-        for (int i = 0; i < 3; i++) ms[i] = acc[i] / (reps > 0 ? reps : 1);
-        for (auto& x : e) (void)hipEventDestroy(x);
-        return;
-    }
     bool all_planned = true;
     for (int st = 0; st < meta->n_stages; st++) all_planned &= planned_part(meta->stages[st]) >= 0;
     // -hip_halves: the two half-launches of the pipelined schedule (ms[0] = the outer half, ms[1] = the inner one)
     idx_t hq1 = 0, hq2 = 0;
     const int plan_mode_used = (halves && halves_geometry(&hq1, &hq2)) ? 4 : -1;
     for (int r = -1; r < reps; r++) {          // r = -1: warm-up
-        // (stage by stage as run() issues them; ms[0] = the exterior of the LAST stage, ms[0] + ms[1] = the whole step --
-        //  with -hip_ext_streams 2 the slabs run beside the interior and their time is part of ms[1])
+        // (stage by stage as run() issues them; ms[0] = the exterior of the LAST stage, ms[0] + ms[1] = the whole step)
         YKH_HIP(hipEventRecord(e[0], compute_stream));
         if (all_planned) {
             // planned launches: ms[0] = from the start of the last stage's launch until its shell blocks have published their
@@ -152,11 +83,9 @@ void Solution::time_decomposed_step(const bool* has_lo, const bool* has_hi, int 
                 if (shell_event_pending) {
                     shell_event_pending = false;
                     YKH_HIP(hipStreamWaitEvent(comm_stream, ev_shell, 0));
-                } else {
-                    sig_pending = false;
-                    const unsigned* wp = sig_dev + 1;
-                    const unsigned wv = sig_epoch;
-                    launch_wait_words(1, &wp, &wv, sig_dev + 2, 20.0, comm_stream);
+                } else {              // (a plan without shell blocks: the launch itself)
+                    YKH_HIP(hipEventRecord(ev_shell, compute_stream));
+                    YKH_HIP(hipStreamWaitEvent(comm_stream, ev_shell, 0));
                 }
                 if (st == meta->n_stages - 1) YKH_HIP(hipEventRecord(e[1], comm_stream));
             }
@@ -172,16 +101,9 @@ void Solution::time_decomposed_step(const bool* has_lo, const bool* has_hi, int 
         }
         for (int st = 0; st < meta->n_stages; st++) {
             const StageMeta& sm = meta->stages[st];
-            const int mode = exterior_mode(sm);
-            int n_ext = 0;
-            if (mode == 0) launch_exterior(sm, r + 1, ib);
-            else {
-                n_ext = launch_exterior_concurrent(sm, r + 1, ib);
-                if (mode == 1) for (int i = 0; i < n_ext; i++) YKH_HIP(hipStreamWaitEvent(compute_stream, ext_events[i], 0));
-            }
+            launch_exterior(sm, r + 1, ib);
             if (st == meta->n_stages - 1) YKH_HIP(hipEventRecord(e[1], compute_stream));
             launch_interior(sm, r + 1, ib);
-            if (mode == 2) for (int i = 0; i < n_ext; i++) YKH_HIP(hipStreamWaitEvent(compute_stream, ext_events[i], 0));
         }
         YKH_HIP(hipEventRecord(e[2], compute_stream));
         for (int st = 0; st < meta->n_stages; st++)
@@ -240,11 +162,11 @@ int Solution::planned_variant_of(int part) const {
 }
 Solution::LaunchPlan* Solution::get_launch_plan(int part, const bool* has_lo, const bool* has_hi, bool wide_shell, int mode) {
     const KernelVariant& kv = impl.parts[part].variants[planned_variant_of(part)];
-    if (mode < 0) mode = (int)plan_mode;
+    if (mode < 0) mode = 0;
     std::ostringstream ks;
     ks << part << ':' << planned_variant_of(part) << '/' << local_size[0] << 'x' << local_size[1] << 'x' << local_size[2] << '/';
     for (int d = 0; d < 3; d++) ks << (has_lo[d] ? 'l' : '-') << (has_hi[d] ? 'h' : '-');
-    ks << '/' << shell_pct << '/' << mode << '/' << min_exterior << '/' << env->num_cus << '/' << (wide_shell ? wf_ext_[0] + wf_ext_[1] * 1000 + wf_ext_[2] * 1000000 : 0);
+    ks << '/' << mode << '/' << min_exterior << '/' << env->num_cus << '/' << (wide_shell ? wf_ext_[0] + wf_ext_[1] * 1000 + wf_ext_[2] * 1000000 : 0);
     const std::string key = ks.str();
     for (auto& lp : launch_plans) if (lp->key == key) return lp.get();
     BlockPlanIn in;
@@ -256,7 +178,7 @@ Solution::LaunchPlan* Solution::get_launch_plan(int part, const bool* has_lo, co
     in.ty = kv.ty; in.tz = kv.tz;
     in.overhead = kv.xover > 0 ? kv.xover : std::max<idx_t>(1, shared_pad_r_[0] + 1);
     in.ncu = std::max(1, env->num_cus);
-    in.shell_frac = (double)shell_pct / 100.0;
+    in.shell_frac = 0.55;           // the shell in the first of two rounds of equal blocks (35 %: three rounds, measured no better)
     in.mode = mode;
     auto lp = std::make_unique<LaunchPlan>();
     lp->key = key;
@@ -280,10 +202,9 @@ Solution::LaunchPlan* Solution::get_launch_plan(int part, const bool* has_lo, co
     launch_plans.push_back(std::move(lp));
     return launch_plans.back().get();
 }
-void Solution::launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hipStream_t s, bool with_pack) {
+void Solution::launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hipStream_t s) {
     const KernelVariant& kv = impl.parts[part].variants[planned_variant_of(part)];
     if (lp.plan.mode_used == 4) {        // (the two halves back to back, without their exchanges: time_decomposed_step())
-        (void)with_pack;
         launch_planned_half(part, t, lp, 0, s);
         if (signal) { YKH_HIP(hipEventRecord(ev_shell, s)); shell_event_pending = true; }
         launch_planned_half(part, t, lp, 1, s);
@@ -292,11 +213,14 @@ void Solution::launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hi
     PartArgs a;
     fill_part_args(part, t, rank_box(), a);
     a.blk = lp.dev;
-    if (signal && lp.plan.n_signal > 0 && planned_split) {
-        // two launches, an event between them (see planned_split): the shell's rounds, then the rest
+    if (signal && lp.plan.n_signal > 0) {
+        // TWO launches, cut at the end of the round that holds the last shell block, with an event between them that releases the
+        // exchange.  (Round 3 also had a one-launch form whose shell blocks raised a device-side signal that a resident one-wave
+        // waiter polled: the waiter took a wave slot on some CU, a marching block needs ALL registers of a CU, and the 256th block of
+        // a round then ran alone afterwards -- +0.1 ms on a 0.46 ms launch, profiles/r3_overlap.  Deleted in round 5 together with
+        // the in-line pack between the two launches: the pack kernel fits in the 16 VGPRs a marching twin leaves.)
         kv.launch_desc(a, dim3((unsigned)lp.cut, 1, 1), s);
         YKH_HIP(hipGetLastError());
-        if (with_pack && inline_pack) exchange_prepack(s);
         YKH_HIP(hipEventRecord(ev_shell, s));
         shell_event_pending = true;
         if (lp.cut < lp.plan.blocks.size()) {
@@ -305,21 +229,6 @@ void Solution::launch_planned(int part, idx_t t, LaunchPlan& lp, bool signal, hi
             YKH_HIP(hipGetLastError());
         }
         return;
-    }
-    if (signal && lp.plan.n_signal > 0) {
-        if (!sig_dev) {
-            // (zeroed before anything can poll it: a waiter on the comm stream must not read what hipMalloc left there)
-            YKH_HIP(hipMalloc(&sig_dev, 4 * sizeof(unsigned)));
-            YKH_HIP(hipMemsetAsync(sig_dev, 0, 4 * sizeof(unsigned), s));
-            YKH_HIP(hipStreamSynchronize(s));
-            sig_count = sig_epoch = 0;
-        }
-        sig_count += (unsigned)lp.plan.n_signal;
-        a.sig = sig_dev;
-        a.sig_goal = sig_count;
-        a.sig_epoch = ++sig_epoch;
-        sig_pending = true;
-        sig_used = true;
     }
     kv.launch_desc(a, dim3((unsigned)lp.plan.blocks.size(), 1, 1), s);
     YKH_HIP(hipGetLastError());

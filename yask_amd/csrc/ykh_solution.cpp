@@ -105,7 +105,7 @@ Solution::Solution(std::shared_ptr<Env> e, const SolnImpl& im) : env(e), impl(im
 Solution::~Solution() {
     drop_step_graphs();
     drop_launch_plans();
-    if (sig_dev) (void)hipFree(sig_dev);
+    if (lockstep_dev) (void)hipFree(lockstep_dev);
     free_halo_buffers();
     vars.clear();
     scratch_vars.clear();
@@ -113,9 +113,6 @@ Solution::~Solution() {
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_shell) (void)hipEventDestroy(ev_shell);
     if (ev_b) (void)hipEventDestroy(ev_b);
-    if (ev_stage) (void)hipEventDestroy(ev_stage);
-    for (auto e : ext_events) if (e) (void)hipEventDestroy(e);
-    for (auto st : ext_streams) if (st) (void)hipStreamDestroy(st);
     for (auto& ph : phase_pool)
         for (auto e : ph.e) if (e) (void)hipEventDestroy(e);
     for (auto e : step_events) if (e) (void)hipEventDestroy(e);
@@ -144,15 +141,7 @@ void Solution::synchronize() {
 // Errors raised on the device while a call's work ran (a waiter that gave up): turned into an exception by the call that queued the
 // work, once its streams have drained -- the error words are always consumed by the call that raised them, so that the next call
 // does not start with every wait returning at once (exchange_halos() used to return success with stale halos).
-void Solution::check_async_errors(const char* who, bool sig_used) {
-    if (sig_used && sig_dev) {
-        unsigned err = 0;
-        YKH_HIP(hipMemcpy(&err, sig_dev + 2, sizeof(err), hipMemcpyDeviceToHost));
-        if (err) {
-            (void)hipMemset(sig_dev + 2, 0, sizeof(unsigned));
-            YKH_THROW(std::string(who) + ": a halo exchange waited in vain for the shell blocks of a planned launch (device-side signal timed out)");
-        }
-    }
+void Solution::check_async_errors(const char* who) {
     if (env->nranks > 1 && env->exch_check && env->exch_check(env->user) != 0)
         YKH_THROW(std::string(who) + ": the halo transport reports a failed exchange");
 }
@@ -218,9 +207,9 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
     const char* bool_opts[] = {"overlap_comms", "use_shm", "use_device_mpi", "force_scalar_exchange", "force_scalar",
                                "bind_inner_threads", "bundle_allocs", "init_scratch_vars", "auto_tune",
                                "allow_addl_padding", "round_up_temporal_angles", "print_suffixes", "verbose",
-                               "exchange_halos", "auto_tune_each_stage", "trace", "hip_direct_halo", "hip_thin_slab_point_kernel", "hip_round_launches",
-                               "hip_step_timers", "hip_phase_timers", "hip_fast_div", "hip_planned_launch", "hip_planned_split", "hip_inline_pack", "hip_wf_ext_always", "hip_halves"};
-    const char* int_opts[] = {"hip_shell_pct", "hip_plan_mode", "hip_placement_trials", "hip_var_skew", "hip_step_graphs", "hip_pitch_extra", "hip_ext_streams", "hip_comm_cus", "hip_fuse_steps", "hip_overlap_splits", "min_exterior", "max_threads", "outer_threads", "inner_threads", "numa_pref",
+                               "exchange_halos", "auto_tune_each_stage", "trace", "hip_direct_halo", "hip_thin_slab_point_kernel",
+                               "hip_step_timers", "hip_phase_timers", "hip_fast_div", "hip_planned_launch", "hip_halves"};
+    const char* int_opts[] = {"hip_placement_trials", "hip_step_graphs", "hip_fuse_steps", "min_exterior", "max_threads", "outer_threads", "inner_threads", "numa_pref",
                               "auto_tune_radius", "thread_divisor", "block_threads", "hip_xchunk", "device_thread_limit"};
     const char* dbl_opts[] = {"auto_tune_trial_secs"};
     const char* str_opts[] = {"auto_tune_targets", "hip_variant"};
@@ -244,14 +233,10 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                     else if (b == "hip_step_timers") step_timers = val;
                     else if (b == "hip_phase_timers") phase_timers = val;
                     else if (b == "hip_planned_launch") planned_launch = val;
-                    else if (b == "hip_planned_split") planned_split = val;
-                    else if (b == "hip_inline_pack") inline_pack = val;
                     else if (b == "hip_halves") halves = val;
-                    else if (b == "hip_wf_ext_always") { wf_ext_always = val; invalidate(); }
                     else if (b == "trace") env->trace = val;
                     else if (b == "hip_direct_halo") { direct_halo = val; invalidate(); }
                     else if (b == "hip_thin_slab_point_kernel") thin_slab_point_kernel = val;
-                    else if (b == "hip_round_launches") round_launches = val;
                     else if (b == "hip_fast_div") { fast_div = val; invalidate(); }
                     else ignored_opts[b] = val ? "true" : "false";
                 }
@@ -268,17 +253,10 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
                 if (!next_val(v) || !parse_idx(v, n)) YKH_THROW("option '-" + opt + "' requires an integer value");
                 handled = true;
                 if (opt == "min_exterior") { min_exterior = n; drop_launch_plans(); }
-                else if (opt == "hip_shell_pct") { shell_pct = std::min<idx_t>(95, std::max<idx_t>(5, n)); drop_launch_plans(); }
-                else if (opt == "hip_plan_mode") { plan_mode = std::min<idx_t>(3, std::max<idx_t>(0, n)); drop_launch_plans(); }
                 else if (opt == "hip_xchunk") xchunk_override = n;
-                else if (opt == "hip_overlap_splits") overlap_splits = std::max<idx_t>(1, n);
                 else if (opt == "hip_fuse_steps") fuse_steps = n;
-                else if (opt == "hip_comm_cus") comm_cus = std::max<idx_t>(0, n);
-                else if (opt == "hip_pitch_extra") { pitch_extra = std::max<idx_t>(0, n); invalidate(); }
                 else if (opt == "hip_step_graphs") step_graphs = n;
                 else if (opt == "hip_placement_trials") { placement_trials = std::max<idx_t>(1, n); invalidate(); }
-                else if (opt == "hip_var_skew") { var_skew = std::max<idx_t>(0, n); for (auto& v : vars) v->release(); for (auto& v : scratch_vars) v->release(); invalidate(); }
-                else if (opt == "hip_ext_streams") ext_streams_mode = std::min<idx_t>(2, std::max<idx_t>(0, n));
                 else ignored_opts[opt] = v;
             }
         if (handled) continue;
@@ -329,8 +307,8 @@ std::string Solution::apply_command_line_options(const std::vector<std::string>&
             };
             if (didx == 100) {
                 // (with neighbours the number of wave-front steps sets the width of halos and pads: prepare_solution() again)
-                if (f == "b") { if (block_size[0] != n && (env->nranks > 1 || wf_ext_always)) invalidate(); block_size[0] = n; }
-                else if (f == "Mb") { if (mega_block_size[0] != n && (env->nranks > 1 || wf_ext_always)) invalidate(); mega_block_size[0] = n; }
+                if (f == "b") { if (block_size[0] != n && env->nranks > 1) invalidate(); block_size[0] = n; }
+                else if (f == "Mb") { if (mega_block_size[0] != n && env->nranks > 1) invalidate(); mega_block_size[0] = n; }
                 else ignored_opts[opt] = v;
             }
             else if (didx == -1) { for (int d = 0; d < ndd; d++) apply(d); if (has_outer) apply(3); }
@@ -381,28 +359,15 @@ std::string Solution::get_command_line_help() const {
           " -[no-]hip_fast_div                fp32 divisions as a * v_rcp_f32(b), <= 1.5 ulp, in the kernel shapes that have such a\n"
           "                                   form (ssg's defaults: 8 divisions per point were a third of the instructions); off: the\n"
           "                                   correctly rounded shapes, the reference's own arithmetic (default on)\n"
-          " -[no-]hip_round_launches          more tiles than CUs: one launch per CU-filling round of tile rows (default on)\n"
           " -[no-]hip_direct_halo             x-face halos of full-dim vars are sent/received in place (default on)\n"
           " -[no-]hip_thin_slab_point_kernel  thin y/z exterior slabs run on the point kernel (default on)\n"
-          " -[no-]hip_planned_split           planned launches go out as two launches with an event behind the shell's rounds (default on;\n"
-          "                                   off: one launch, the exchange released by a device-side signal that a resident wave polls)\n"
-          " -[no-]hip_inline_pack             ... and the halos are packed between the two, on the compute stream (default off: the\n"
-          "                                   pack kernel runs beside the second launch on the communication stream)\n"
-          " -[no-]hip_halves                  decomposed runs: a stage is TWO launches in regular order, the outer and the inner half of the\n"
-          "                                   x range, each followed by the exchange of its own part of the faces, which travels while the\n"
-          "                                   other half is computed (no shell-first order; needs face-only reads of the written vars and a\n"
-          "                                   y or z decomposition; falls back to planned launches elsewhere; default off)\n"
-          " -[no-]hip_planned_launch          decomposed runs: the rank box as ONE launch of the marching kernel, shell blocks first,\n"
-          "                                   the exchange released from the device when they are done (default on; off: exterior\n"
-          "                                   slabs, then the interior in -hip_overlap_splits launches)\n"
-          " -hip_shell_pct <n>                planned launches: the shell is to be done after n % of the launch (default 55: two rounds)\n"
-          " -hip_plan_mode <0|1|2|3>          planned launches: 0 = rounds of equal blocks, shell first (default); 1 / 2 = the first planner;\n"
-          "                                   3 = the blocks of 0 in the order of a regular launch (diagnostic: the exchange starts late)\n"
-          "                                   (thin x slabs, per-CU budgets / uniform interior chunks; measured slower, kept for A/B)\n"
-          " -hip_overlap_splits <n>           slab schedule: interior launches per step when halos are overlapped (default 1)\n"
-          " -hip_ext_streams <0|1|2>          exterior slabs: 0 one after another (default), 1 side by side on their own streams,\n"
-          "                                   2 side by side and beside the interior\n"
-          " -hip_comm_cus <n>                 CUs the overlapped interior launches leave to the send/recv kernels (default 0)\n"
+          " -[no-]hip_planned_launch          decomposed runs (y or z neighbours): a stage whose one part runs on a marching kernel goes out\n"
+          "                                   as whole-box launches of equal blocks instead of exterior slabs + interior (default on).\n"
+          " -[no-]hip_halves                  ... as TWO launches in regular order, the outer and the inner half of the x range, each\n"
+          "                                   followed by the exchange of its own part of the faces, which travels while the other half is\n"
+          "                                   computed (default on; needs face-only reads of the written vars).  -no-hip_halves: ONE plan of\n"
+          "                                   equal blocks, the blocks a neighbour needs first, the exchange released by an event behind\n"
+          "                                   their rounds.  -no-overlap_comms: the whole box, then the exchange.\n"
           " CPU-only options (-Mb -mb -nb -pb -max_threads -outer_threads -inner_threads -numa_pref\n"
           "  -bind_inner_threads -bundle_allocs -use_shm -use_device_mpi ...) are accepted and ignored.\n";
     return os.str();
@@ -487,7 +452,7 @@ void Solution::prepare() {
                 for (auto* list : {&vars, &scratch_vars})
                     for (auto& v : *list)
                         if (!v->fixed_size && v->uses_domain[d]) wf_angle_[d] = std::max({wf_angle_[d], v->halo_l[d], v->halo_r[d]});
-            const bool split = d < ndd && !has_outer && (num_ranks[d] > 1 || (wf_ext_always && env->nranks == 1));
+            const bool split = d < ndd && !has_outer && num_ranks[d] > 1;
             wf_ext_[d] = (split && shifts > 0) ? wf_angle_[d] * shifts : 0;
         }
     }
@@ -781,8 +746,7 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
             // rounds (a 576-tile plane on 256 CUs would otherwise run 3 rounds for 2.25 rounds of work),
             // while every chunk re-loads the x-halo planes of its neighbours (cost ~ xhalo / chunk length).
             const idx_t tiles = (idx_t)a.ntz * a.nty;
-            // (interior of an overlapped exchange: leave -hip_comm_cus CUs to the send/recv kernels)
-            const idx_t cus = std::max<idx_t>(1, env->num_cus - (launching_interior ? std::min<idx_t>(comm_cus, env->num_cus / 2) : 0));
+            const idx_t cus = std::max<idx_t>(1, env->num_cus);
             idx_t xhalo = shared_pad_l_[0] + shared_pad_r_[0];
             double best_eff = -1;
             idx_t best_n = 1;
@@ -799,7 +763,7 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
         xc = std::max<idx_t>(1, std::min(xc, nx));
         a.xchunk = (int)xc;
         a.nxc = (int)ceil_div(nx, xc);
-        if (round_launches) {
+        {
             // More tiles than CUs: one launch per round of whole tile rows, so that the tiles of a round start
             // together and march in step (neighbouring tiles then touch the same DRAM pages and L2 lines at
             // about the same time; tiles of a second round started one by one drift apart).
@@ -817,6 +781,11 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
             }
         }
         dim3 grid((unsigned)((idx_t)a.ntz * a.nty * a.nxc), 1, 1);
+        if (kv.lockstep && (grid.x & 7) == 0) {
+            if (!lockstep_dev) YKH_HIP(hipMalloc(&lockstep_dev, 8 * 32 * sizeof(unsigned)));
+            YKH_HIP(hipMemsetAsync(lockstep_dev, 0, 8 * 32 * sizeof(unsigned), s));
+            a.sig = lockstep_dev;
+        }
         kv.launch(a, grid, s);
     } else {
         kv.launch(a, point_grid(box, a.lane_dim), s);
@@ -938,8 +907,7 @@ void Solution::run(idx_t first_step, idx_t last_step) {
     }
     phase_used = 0;
     cur_phase = nullptr;
-    sig_pending = shell_event_pending = prepacked_ = false;
-    sig_used = false;
+    shell_event_pending = false;
     // Wave-front temporal tiling (-Mbt / -bt > 1): groups of steps go slab by slab (run_wavefront below).  Single rank only:
     // with neighbours the halos would have to be wf_steps x wider (the reference extends them, setup.cpp:863-1020).
     const idx_t wf_steps = std::max<idx_t>(mega_block_size[0], block_size[0]);
@@ -1027,8 +995,8 @@ void Solution::run(idx_t first_step, idx_t last_step) {
                 // (the reference's exterior-first order, context.cpp:377-478, without separate launches)
                 LaunchPlan* lp = get_launch_plan(pl_part, lo, hi);
                 phase_mark(PH_EXT0, compute_stream);
-                note_stage_written(sm, t);          // (host bookkeeping: the dirty flags the in-line pack goes by)
-                launch_planned(pl_part, t, *lp, /*signal=*/true, compute_stream, /*with_pack=*/true);
+                note_stage_written(sm, t);
+                launch_planned(pl_part, t, *lp, /*signal=*/true, compute_stream);
                 exchange_halos(t, st, /*start_only=*/true, false);       // (marks PH_EXT1 on the comm stream, after its wait)
                 phase_mark(PH_INT1, compute_stream);
                 exchange_halos(t, st, false, /*finish_only=*/true);
@@ -1036,30 +1004,19 @@ void Solution::run(idx_t first_step, idx_t last_step) {
                 cur_phase = nullptr;
                 continue;
             }
-            int n_ext = 0;
-            const int ext_mode = overlap ? exterior_mode(sm) : 0;
             if (overlap) {
                 // exterior slabs first (context.cpp:377-444), then start the exchange, then the interior
                 phase_mark(PH_EXT0, compute_stream);
-                if (ext_mode == 0) launch_exterior(sm, t, interior_box);
-                else {
-                    n_ext = launch_exterior_concurrent(sm, t, interior_box);
-                    if (ext_mode == 1)
-                        for (int i = 0; i < n_ext; i++) YKH_HIP(hipStreamWaitEvent(compute_stream, ext_events[i], 0));
-                }
-                phase_mark(PH_EXT1, compute_stream);     // (mode 2: the slabs run beside the interior; their time shows there)
+                launch_exterior(sm, t, interior_box);
+                phase_mark(PH_EXT1, compute_stream);
             } else {
                 phase_mark(PH_EXT1, compute_stream);      // (no split: the whole box counts as interior time)
                 for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, rb, compute_stream);
             }
             note_stage_written(sm, t);
             if (multi) {
-                if (ext_mode == 2)      // the exchange starts when the slabs are done, whatever the compute stream is doing
-                    for (int i = 0; i < n_ext; i++) YKH_HIP(hipStreamWaitEvent(comm_stream, ext_events[i], 0));
                 exchange_halos(t, st, /*start_only=*/true, false);
                 if (overlap) launch_interior(sm, t, interior_box);
-                if (ext_mode == 2)
-                    for (int i = 0; i < n_ext; i++) YKH_HIP(hipStreamWaitEvent(compute_stream, ext_events[i], 0));
                 phase_mark(PH_INT1, compute_stream);
                 exchange_halos(t, st, false, /*finish_only=*/true);
                 phase_mark(PH_WAIT1, compute_stream);     // completes when the halos have landed (stream waits on ev_b)
@@ -1079,7 +1036,7 @@ void Solution::run(idx_t first_step, idx_t last_step) {
     }
     YKH_HIP(hipStreamSynchronize(compute_stream));
     if (multi) YKH_HIP(hipStreamSynchronize(comm_stream));
-    check_async_errors("run_solution()", sig_used);
+    check_async_errors("run_solution()");
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stats.elapsed_secs += secs;
     stats.halo_secs += halo_secs;

@@ -270,6 +270,12 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
     constexpr int TRIP = PD * CD / ce_gcd(PD, CD);    // planes per loop trip (the register sets rotate)
     constexpr bool TAILOPT = ((NTH >> 6) & 1) != 0;   // bit 6: cheap tail planes (see plane())
     constexpr bool WT_OUT = ((NTH >> 7) & 1) != 0 && sizeof(V) == 16;     // bit 7 ("_wt"): write-through (sc1) output stores, see stv_b_wt
+    // bits 8-10 ("_ls<K>", profiling builds only, round 5): soft LOCK-STEP of the workgroups that share an XCD -- every K planes wave 0 counts
+    // the workgroup in at a counter of its XCD (an L2 atomic) and waits, for a bounded number of polls, until all
+    // of the XCD's workgroups of the launch have arrived; the plane's own barrier holds the other waves.  The question (VERDICT r04 next
+    // #8): do tiles that march within K planes of each other stop re-fetching the halo lines their neighbours streamed?  a.sig = the
+    // 8 counters (32 words apart), zeroed by the host before the launch.
+    constexpr int LS_K = ((NTH >> 8) & 7) == 0 ? 0 : (1 << (((NTH >> 8) & 7) - 1));          // 1 -> 1, 2 -> 2, 3 -> 4, 4 -> 8, 5 -> 16
     static_assert(CD == 1 || XH > 0, "operand prefetch depth 2 needs a future x range");
     static_assert(!C::R.mixed, "linear form has a mixed-offset term");
     static_assert(NG <= MAX_GROUPS, "too many access groups");
@@ -615,6 +621,29 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::false_type NoTail;
+    [[maybe_unused]] auto xcd_sync = [&](int x) {
+        if constexpr (LS_K > 0 && !DESC) {
+            const int k = (x - xs) / LS_K;                       // uniform
+            if (a.sig && k > 0 && (x - xs) % LS_K == 0 && threadIdx.x == 0) {
+                unsigned* c = a.sig + (blockIdx.x & 7) * 32;
+                const unsigned goal = (unsigned)k * (gridDim.x >> 3);
+                // (agent scope: the add is an L2 atomic, the poll an sc1 load that bypasses this CU's L1.  A first version polled at
+                //  workgroup scope: hipcc turned its fetch_add(0) into an sc0 LOAD, which hits the L1 and never sees the other
+                //  workgroups' increments -- every wait then ran into the poll limit, profiles/r5_3axis_lockstep)
+                __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int spin = 0; spin < 4096; spin++) {
+                    if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= goal) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
+    };
+    if constexpr (LS_K > 0 && !TAILOPT && ROT == ROT_MOVE) {
+        for (int x = xs; x < xlast; x += TRIP) {
+            xcd_sync(x);
+            static_for<TRIP>([&](auto sc) { plane(x + decltype(sc)::value, I0{}, sc, NoTail{}); rotate(); });
+        }
+    } else
     if constexpr (TAILOPT) {
         // _tl shapes: the main loop runs whole trips of full planes only (its code is exactly the plain shape's); what is left of
         // the block -- fewer than a trip of full planes and the XH tail planes -- goes plane by plane with moved queues, and the

@@ -127,9 +127,11 @@ KernelVariant starlin_variant() {
     static const std::string name = std::string(ABL ? "abl" + std::to_string(ABL) + "_" : "") + "starlin_v" + std::to_string(VZ) +
                                     "_z" + std::to_string(C::TZ) + "_y" + std::to_string(C::TY) + "_r" +
                                     std::to_string(RY) + (ROT == ROT_UNROLL ? "_u" : (ROT == ROT_TRIP ? "_t" : (ROT == ROT_TRIP2 ? "_t2" : "_m"))) + ((NTH & 1) ? "_nt" : "") +
-                                    (((NTH >> 1) & 3) ? "_hl" + std::to_string((NTH >> 1) & 3) : "") + ((NTH & 32) ? "_pd3" : ((NTH & 8) ? "_pd2" : "")) + ((NTH & 16) ? "_cd2" : "") + ((NTH & 64) ? "_tl" : "") + ((NTH & 128) ? "_wt" : "") + "_w" +
+                                    (((NTH >> 1) & 3) ? "_hl" + std::to_string((NTH >> 1) & 3) : "") + ((NTH & 32) ? "_pd3" : ((NTH & 8) ? "_pd2" : "")) + ((NTH & 16) ? "_cd2" : "") + ((NTH & 64) ? "_tl" : "") + ((NTH & 128) ? "_wt" : "") +
+                                    (((NTH >> 8) & 7) ? "_ls" + std::to_string(1 << (((NTH >> 8) & 7) - 1)) : "") + "_w" +
                                     std::to_string(MINW) + "_c" + std::to_string(CH);
     KernelVariant kv{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_starlin<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL>};
+    kv.lockstep = ((NTH >> 8) & 7) != 0;
     kv.vz = VZ;
     kv.func = reinterpret_cast<const void*>(&starlin_kernel<P, VZ, TZL, TYL, RY, ROT, NTH, MINW, CH, ABL>);
     kv.xover = C::XH + 1;                 // a block runs XH plane-iterations before its first output plane (+ the queue loads)

@@ -157,7 +157,7 @@ bool Solution::step_graph_wanted() const {
 std::string Solution::step_graph_key(idx_t t, idx_t dir, idx_t steps) const {
     std::ostringstream os;
     const idx_t P = slot_period();
-    os << ((t % P) + P) % P << '/' << dir << '/' << steps << '/' << round_launches << thin_slab_point_kernel << force_scalar;
+    os << ((t % P) + P) % P << '/' << dir << '/' << steps << '/' << thin_slab_point_kernel << force_scalar;
     for (size_t p = 0; p < part_variant.size(); p++) os << ',' << part_variant[p] << ':' << part_xchunk[p];
     for (int d = 0; d < MAX_API_DOMAIN_DIMS; d++) os << ';' << local_size[d] << '+' << rank_ofs[d];
     for (auto& v : vars) os << '|' << v->dptr << '.' << v->nslots;

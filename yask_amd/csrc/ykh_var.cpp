@@ -136,7 +136,7 @@ void Var::compute_geometry() {
             pad_l[d] = round_up(pad_l[d], zal);
             idx_t vz = 16 / eb;
             idx_t pr = round_up(pad_r[d], vz);
-            idx_t pitch = round_up(pad_l[d] + dom_size[d] + pr, zal) + soln->pitch_extra * zal;
+            idx_t pitch = round_up(pad_l[d] + dom_size[d] + pr, zal);
             pad_r[d] = pitch - pad_l[d] - dom_size[d];
         }
         alloc[d] = pad_l[d] + dom_size[d] + pad_r[d];
@@ -217,13 +217,9 @@ void Var::allocate() {
     release();
     size_t nb = bytes();
     if (nb == 0) nb = 256;
-    // -hip_var_skew n: var k of the solution starts (k * n mod 64) x 256 B into its allocation, so that the same logical point of
-    // the solution's arrays -- which a multi-var kernel reads at the same time -- does not start in the same position of the
-    // allocation granule in all of them (tools/placement_probe.py)
-    const size_t skew = soln->var_skew > 0 ? (size_t)((ordinal * soln->var_skew) % 64) * 256 : 0;
     void* ap = nullptr;
-    YKH_HIP(hipMalloc(&ap, nb + skew));
-    adopt_storage(own_allocation(ap), ap, (char*)ap + skew, nb);
+    YKH_HIP(hipMalloc(&ap, nb));
+    adopt_storage(own_allocation(ap), ap, ap, nb);
     // Zero on the solution's own stream: hipMemset() runs on the NULL stream, which the solution's
     // non-blocking streams do not synchronise with -- a multi-GB memset was still clearing the tail of the
     // allocation while the first init kernel had already written it (seen at >= 512^3).

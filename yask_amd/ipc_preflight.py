@@ -26,7 +26,7 @@ def main():
     assert world == grid[0] * grid[1] * grid[2], (world, grid)
     env.transport_loopback(1 << 16)
     assert env.sum_over_ranks(1) == world
-    for opts in ("-overlap_comms -hip_planned_launch", "-overlap_comms -hip_halves"):
+    for opts in ("-overlap_comms -hip_planned_launch -no-hip_halves", "-overlap_comms -hip_halves"):
         soln = fac.new_solution(env)
         soln.set_overall_domain_size_vec([96 * grid[0], 48 * grid[1], 64 * grid[2]])
         soln.set_num_ranks_vec(grid)
