@@ -17,8 +17,12 @@ from pathlib import Path
 import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
-BASE = "starlin_v2_z128_y32_r4_m_nt_w2_c4"
-LS = [BASE.replace("_nt_", f"_nt_ls{k}_") for k in (1, 2, 4, 8, 16)]
+BASES = {"3axis": "starlin_v2_z128_y32_r4_m_nt_w2_c4", "iso3dfd": "starlin_v4_z128_y32_r2_t2_nt_pd2_tl_w2_c2"}
+FIELD = {"3axis": "A", "iso3dfd": "p"}
+
+
+def ls_names(base):
+    return [base.replace("_w2_", f"_ls{k}_w2_") for k in (1, 2, 4, 8, 16, 32, 64)]
 
 
 def make(fac, n, opts="-no-auto_tune"):
@@ -36,17 +40,20 @@ def main():
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--fetch", default=None)
+    ap.add_argument("--stencil", default="3axis", choices=sorted(BASES))
+    ap.add_argument("--only", type=int, nargs="*", default=None, help="lock-step periods to time (default: all compiled)")
     args = ap.parse_args()
     from yask_amd import yk_factory
     from yask_amd.kernel import yk_env
     yk_env.disable_debug_output()
-    fac = yk_factory("3axis")
+    fac = yk_factory(args.stencil)
+    BASE, LS = BASES[args.stencil], ls_names(BASES[args.stencil])
     s = make(fac, args.size)
     names = s.get_kernel_variant_names(0)
     if args.fetch:
         s.time_part(0, names.index(args.fetch), 0, 0, 6)
         return
-    shapes = [BASE] + [x for x in LS if x in names]
+    shapes = [BASE] + [x for x in LS if x in names and (not args.only or int(x.split("_ls")[1].split("_")[0]) in args.only)]
     if len(shapes) == 1:
         raise SystemExit("no _ls shapes in this library: build one with tools/build_prof_lib.sh 3axis and set YASK_HIP_LIB_DIR")
     idx = {x: names.index(x) for x in shapes}
@@ -67,16 +74,16 @@ def main():
         for x in shapes:
             q = make(fac, size, f"-no-auto_tune -hip_variant {x}")
             q.run_solution(0, 2)
-            v = q.get_var("A")
+            v = q.get_var(FIELD[args.stencil])
             t = v.get_last_valid_step_index()
             res.append(v.get_elements_in_slice([t, 0, 0, 0], [t, size[0] - 1, size[1] - 1, size[2] - 1])[0].copy())
             q.end_solution()
         same["x".join(map(str, size))] = all(np.array_equal(res[0], r) for r in res[1:])
     out["bit_identical_to_base"] = same
     print(json.dumps(same), flush=True)
-    p = Path(__file__).resolve().parents[1] / "gpurun_out" / "r5d"
+    p = Path(__file__).resolve().parents[1] / "gpurun_out" / "r5_lockstep"
     p.mkdir(parents=True, exist_ok=True)
-    json.dump(out, open(p / "lockstep_probe.json", "w"), indent=1)
+    json.dump(out, open(p / f"lockstep_probe_{args.stencil}.json", "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -23,7 +23,7 @@ const SolnImpl& ykh_solution_impl() {
         s3axis_variants_k3(p);
         s3axis_variants_k4(p);
         p.set_default("starlin_v2_z64_y32_r2_u_nt_tl_w2_c4");      // cheap tail planes: 512^3 0.395 vs 0.412 ms (gpurun_out/r3j), bit-identical
-        p.set_large_grid("starlin_v2_z128_y32_r4_m_nt_w2_c4");
+        p.set_large_grid("starlin_v2_z128_y32_r4_m_nt_ls64_w2_c4");     // (round 4: the same shape without the lock-step)
         s.parts.push_back(p);
         return s;
     }();

@@ -18,6 +18,10 @@ void iso3dfd_variants_k4(PartImpl& p) {
 #endif
     p.variants.push_back(starlin_variant_planned<part_1, 4, 32, 16, 2, ROT_TRIP2, 9 | 64, 2, 2>());      // 256 VGPRs, no scratch
     p.variants.push_back(starlin_variant_planned<part_1, 4, 32, 16, 2, ROT_TRIP, 9 | 64, 2, 2>());
+#ifdef YKH_PROFILING      // round 5 A/B: the default shape with the XCD lock-step every 16 / 64 planes (ykh_starlin.hpp xcd_sync)
+    p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_TRIP2, 9 | 64 | (5 << 8), 2, 2>());
+    p.variants.push_back(starlin_variant<part_1, 4, 32, 16, 2, ROT_TRIP2, 9 | 64 | (7 << 8), 2, 2>());
+#endif
 #ifdef YKH_PROFILING      // write-through output stores: measured 1-12 % slower, profiles/r4_wt
     p.variants.push_back(starlin_variant_planned<part_1, 4, 32, 16, 2, ROT_TRIP2, 9 | 64 | 128, 2, 2>());
 #endif

@@ -54,7 +54,7 @@ struct KernelVariant {
     void (*launch_desc)(const PartArgs& a, dim3 grid, hipStream_t s) = nullptr;
     const void* func_desc = nullptr;
     int xover = 0;                // plane-iterations of overhead per block (prologue; the planner's cost model)
-    bool lockstep = false;        // "_ls<K>" shapes (profiling builds): PartArgs::sig = 8 zeroed per-XCD counters, see starlin_kernel
+    bool lockstep = false;        // "_ls<K>" shapes: PartArgs::sig = 8 zeroed per-XCD counters, see starlin_kernel
 };
 // bytes of scratch (private segment) per thread of a variant's kernel; > 0 means hipcc spilled registers
 size_t variant_scratch_bytes(const KernelVariant& kv);
@@ -456,7 +456,9 @@ public:
     bool planned_launch = true;        // -[no-]hip_planned_launch
     struct LaunchPlan { std::string key; BlockPlan plan; BlockDesc* dev = nullptr; size_t cut = 0; };      // cut: end of the round that holds the last shell block
     std::vector<std::unique_ptr<LaunchPlan>> launch_plans;
-    unsigned* lockstep_dev = nullptr;  // per-XCD arrival counters of the "_ls" experiment shapes (8 x 32 words)
+    unsigned* lockstep_dev = nullptr;  // per-XCD arrival counters of the "_ls<K>" shapes (8 x 32 words), zeroed before each such launch
+    std::map<const void*, int> resident_cache_;
+    int resident_blocks(const KernelVariant& kv);
     bool shell_event_pending = false;  // ev_shell was recorded behind the shell part of the launch just issued
     hipEvent_t ev_shell = nullptr;
     void exchange_build_and_pack(hipStream_t st);
@@ -501,7 +503,7 @@ public:
     Stats get_stats();       // returns and clears, like soln_apis.cpp:349-562
     void reset_auto_tuner(bool enable);
     void run_auto_tuner_now();
-    void tune_variants(bool quick);
+    void tune_variants(bool quick, bool fresh_storage = false);      // fresh_storage: no var holds data yet (prepare_solution() allocated them all)
     idx_t compare_data(const Solution& ref, double epsilon) const;
     void copy_vars_to_device() {}
     void copy_vars_from_device() {}

@@ -477,12 +477,13 @@ void Solution::prepare() {
     }
     for (auto& v : scratch_vars) { v->compute_geometry(); need_alloc.push_back(v.get()); v->l1_norm = 0; }
     // (the placement search runs trial steps: only when no var of the solution holds data from before this call)
-    bool placed = false;
+    bool placed = false, all_fresh = false;
     {
         size_t total = 0, movable = scratch_vars.size();
         for (auto& v : vars) movable += v->fixed_size ? 0 : 1;
         for (auto* v : need_alloc) { v->allocate(); total += v->bytes(); }
-        placed = !need_alloc.empty() && need_alloc.size() == movable && total >= ((size_t)256 << 20);
+        all_fresh = !need_alloc.empty() && need_alloc.size() == movable;
+        placed = all_fresh && total >= ((size_t)256 << 20);
         for (auto& v : vars) if (v->fuse_group) placed = false;      // storage shared with another solution's var stays where it is
     }
     free_halo_buffers();
@@ -637,7 +638,7 @@ void Solution::prepare() {
     // Grids too small to give every CU a default tile: which family wins depends on the size (iso3dfd 64^3: point
     // kernel 39 Gpoints/s vs 6.5 for the default marching shape; 256^3: star25d 290 vs 209), so time them once.
     // (-no-auto_tune switches this off too: the static defaults are then reproducible run to run)
-    else if (tune_at_prepare && (impl.select_by_timing || small_grid) && variant_override.empty() && !force_scalar) tune_variants(true);
+    else if (tune_at_prepare && (impl.select_by_timing || small_grid) && variant_override.empty() && !force_scalar) tune_variants(true, all_fresh);
     if (env->exch_reset && env->nranks > 1) env->exch_reset(env->user);      // (var storage may have moved: tune_placement())
     for (auto& h : after_prepare) h(*this);
 }
@@ -708,6 +709,16 @@ void Solution::fill_part_args(int part, idx_t t, const Box& box, PartArgs& a) co
     a.dom_y1 = (int)(ndd > 1 ? local_size[1] : 1);
     a.dom_z1 = (int)(ndd > 2 ? local_size[2] : 1);
     a.lane_dim = std::max(0, std::min(2, ndd - 1));
+}
+
+// workgroups of a kernel shape that one CU holds at a time (registers, LDS, waves), asked of the runtime once per shape
+int Solution::resident_blocks(const KernelVariant& kv) {
+    auto it = resident_cache_.find(kv.func);
+    if (it != resident_cache_.end()) return it->second;
+    int n = 0;
+    if (!kv.func || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kv.func, kv.threads, kv.lds_bytes) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    resident_cache_[kv.func] = n;
+    return n;
 }
 
 void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t, const Box& box_in, hipStream_t s) {
@@ -781,7 +792,11 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
             }
         }
         dim3 grid((unsigned)((idx_t)a.ntz * a.nty * a.nxc), 1, 1);
-        if (kv.lockstep && (grid.x & 7) == 0) {
+        // "_ls<K>" shapes: the workgroups of an XCD keep within K planes of each other (starlin_kernel, xcd_sync).  Only where the
+        // hand-shake can complete: block i on XCD i % 8 with equal shares (grid a multiple of 8), every block of the launch resident at
+        // once, and every block with the same number of planes to march (equal x-chunks) -- else the shape runs as its plain sibling.
+        if (kv.lockstep && (grid.x & 7) == 0 && nx % a.nxc == 0 && (idx_t)a.xchunk * a.nxc == nx &&
+            (idx_t)grid.x <= (idx_t)resident_blocks(kv) * std::max(1, env->num_cus)) {
             if (!lockstep_dev) YKH_HIP(hipMalloc(&lockstep_dev, 8 * 32 * sizeof(unsigned)));
             YKH_HIP(hipMemsetAsync(lockstep_dev, 0, 8 * 32 * sizeof(unsigned), s));
             a.sig = lockstep_dev;

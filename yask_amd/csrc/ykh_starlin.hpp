@@ -270,12 +270,14 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
     constexpr int TRIP = PD * CD / ce_gcd(PD, CD);    // planes per loop trip (the register sets rotate)
     constexpr bool TAILOPT = ((NTH >> 6) & 1) != 0;   // bit 6: cheap tail planes (see plane())
     constexpr bool WT_OUT = ((NTH >> 7) & 1) != 0 && sizeof(V) == 16;     // bit 7 ("_wt"): write-through (sc1) output stores, see stv_b_wt
-    // bits 8-10 ("_ls<K>", profiling builds only, round 5): soft LOCK-STEP of the workgroups that share an XCD -- every K planes wave 0 counts
-    // the workgroup in at a counter of its XCD (an L2 atomic) and waits, for a bounded number of polls, until all
-    // of the XCD's workgroups of the launch have arrived; the plane's own barrier holds the other waves.  The question (VERDICT r04 next
-    // #8): do tiles that march within K planes of each other stop re-fetching the halo lines their neighbours streamed?  a.sig = the
-    // 8 counters (32 words apart), zeroed by the host before the launch.
-    constexpr int LS_K = ((NTH >> 8) & 7) == 0 ? 0 : (1 << (((NTH >> 8) & 7) - 1));          // 1 -> 1, 2 -> 2, 3 -> 4, 4 -> 8, 5 -> 16
+    // bits 8-10 ("_ls<K>", round 5): soft LOCK-STEP of the workgroups that share an XCD -- every K planes wave 0 counts the workgroup in at
+    // a counter of its XCD (an L2 atomic) and waits, for a bounded number of polls, until all of the XCD's workgroups of the launch have
+    // arrived; the plane's own barrier holds the other waves.  Tiles that march within K planes of each other find the halo lines their
+    // neighbours streamed as interior still in the XCD's 4 MiB L2, and all of them stream the same DRAM pages at the same time: 3axis fp64
+    // 1024^3 fetches 4.4-5.1 % less and runs 4.1 % faster at K = 64, K <= 8 costs more than it saves (profiles/r5_3axis_lockstep).
+    // a.sig = the 8 counters (32 words apart), zeroed by the host before the launch; null = no lock-step (Solution::launch_part_variant
+    // decides: the hand-shake needs every block resident, equal x-chunks, block i on XCD i % 8).
+    constexpr int LS_K = ((NTH >> 8) & 7) == 0 ? 0 : (1 << (((NTH >> 8) & 7) - 1));          // 1 -> 1, 2 -> 2, ... 7 -> 64
     static_assert(CD == 1 || XH > 0, "operand prefetch depth 2 needs a future x range");
     static_assert(!C::R.mixed, "linear form has a mixed-offset term");
     static_assert(NG <= MAX_GROUPS, "too many access groups");
@@ -621,29 +623,31 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::false_type NoTail;
-    [[maybe_unused]] auto xcd_sync = [&](int x) {
+    // Soft lock-step of the XCD's workgroups (LS_K > 0, see above): called at the top of every loop trip (`step` planes); the trip in
+    // which the block crosses a multiple of LS_K planes counts the block in and waits.  A block that once waited in vain (poll limit:
+    // the workgroups are not all resident, or do not sit where blockIdx % 8 says) stops taking part for the rest of its range.
+    [[maybe_unused]] bool ls_dead = false;
+    [[maybe_unused]] auto xcd_sync = [&](int x, int step) {
         if constexpr (LS_K > 0 && !DESC) {
-            const int k = (x - xs) / LS_K;                       // uniform
-            if (a.sig && k > 0 && (x - xs) % LS_K == 0 && threadIdx.x == 0) {
-                unsigned* c = a.sig + (blockIdx.x & 7) * 32;
-                const unsigned goal = (unsigned)k * (gridDim.x >> 3);
-                // (agent scope: the add is an L2 atomic, the poll an sc1 load that bypasses this CU's L1.  A first version polled at
-                //  workgroup scope: hipcc turned its fetch_add(0) into an sc0 LOAD, which hits the L1 and never sees the other
-                //  workgroups' increments -- every wait then ran into the poll limit, profiles/r5_3axis_lockstep)
-                __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (int spin = 0; spin < 4096; spin++) {
-                    if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= goal) break;
-                    __builtin_amdgcn_s_sleep(2);
+            const int d = x - xs, k = d / LS_K;                      // uniform
+            if (a.sig && !ls_dead && k > 0 && d - k * LS_K < step) {
+                if (threadIdx.x == 0) {
+                    unsigned* c = a.sig + (blockIdx.x & 7) * 32;
+                    const unsigned goal = (unsigned)k * (gridDim.x >> 3);
+                    // (agent scope: the add is an L2 atomic, the poll an sc1 load that bypasses this CU's L1.  A first version polled at
+                    //  workgroup scope: hipcc turned its fetch_add(0) into an sc0 LOAD, which hits the L1 and never sees the other
+                    //  workgroups' increments -- every wait then ran into the poll limit, profiles/r5_3axis_lockstep)
+                    __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    int spin = 0;
+                    for (; spin < 400; spin++) {
+                        if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= goal) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (spin == 400) ls_dead = true;            // (thread 0's copy is the one that is read)
                 }
             }
         }
     };
-    if constexpr (LS_K > 0 && !TAILOPT && ROT == ROT_MOVE) {
-        for (int x = xs; x < xlast; x += TRIP) {
-            xcd_sync(x);
-            static_for<TRIP>([&](auto sc) { plane(x + decltype(sc)::value, I0{}, sc, NoTail{}); rotate(); });
-        }
-    } else
     if constexpr (TAILOPT) {
         // _tl shapes: the main loop runs whole trips of full planes only (its code is exactly the plain shape's); what is left of
         // the block -- fewer than a trip of full planes and the XH tail planes -- goes plane by plane with moved queues, and the
@@ -652,13 +656,16 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
         if constexpr (ROT == ROT_TRIP || ROT == ROT_TRIP2) {
             constexpr int K = (ROT == ROT_TRIP2 ? 2 : 1) * (TRIP % 2 == 0 ? TRIP : 2 * TRIP);
             for (; x + K <= xe; x += K) {
+                xcd_sync(x, K);
                 static_for<K>([&](auto sc) { plane(x + decltype(sc)::value, sc, sc, NoTail{}); });
                 rotate_by(std::integral_constant<int, K>{});
             }
         } else if constexpr (ROT == ROT_UNROLL) {
             static_assert(C::UNR % TRIP == 0, "the unroll count must be a multiple of the prefetch trip");
-            for (; x + C::UNR <= xe; x += C::UNR)
+            for (; x + C::UNR <= xe; x += C::UNR) {
+                xcd_sync(x, C::UNR);
                 static_for<C::UNR>([&](auto phc) { plane(x + decltype(phc)::value, phc, phc, NoTail{}); });
+            }
         }
         // (the main loop ran whole trips, so the queues are in canonical order, the prefetch sets and the slab ring continue
         //  from position 0; ROT_MOVE shapes run everything here)
@@ -667,19 +674,24 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
     } else if constexpr (ROT == ROT_MOVE) {
         // PD planes per trip (the prefetch sets alternate); a trip may run past xlast-1: loads are clamped
         // to the allocation and stores are predicated on xo < xe.
-        for (int x = xs; x < xlast; x += TRIP)
+        for (int x = xs; x < xlast; x += TRIP) {
+            xcd_sync(x, TRIP);
             static_for<TRIP>([&](auto sc) { plane(x + decltype(sc)::value, I0{}, sc, NoTail{}); rotate(); });
+        }
     } else if constexpr (ROT == ROT_TRIP || ROT == ROT_TRIP2) {
         constexpr int K = (ROT == ROT_TRIP2 ? 2 : 1) * (TRIP % 2 == 0 ? TRIP : 2 * TRIP);     // even: the two slabs alternate
         for (int x = xs; x < xlast; x += K) {
+            xcd_sync(x, K);
             static_for<K>([&](auto sc) { plane(x + decltype(sc)::value, sc, sc, NoTail{}); });
             rotate_by(std::integral_constant<int, K>{});
         }
     } else {
         // UNR planes per trip (queue rotation by renaming); the last trip may run past xlast-1.
         static_assert(C::UNR % TRIP == 0, "the unroll count must be a multiple of the prefetch trip");
-        for (int x = xs; x < xlast; x += C::UNR)
+        for (int x = xs; x < xlast; x += C::UNR) {
+            xcd_sync(x, C::UNR);
             static_for<C::UNR>([&](auto phc) { plane(x + decltype(phc)::value, phc, phc, NoTail{}); });
+        }
     }
     if constexpr (DESC) block_done(a, bb.flags);
 }

@@ -68,18 +68,21 @@ void Solution::tune_placement() {
     auto attach = [&](const PtrSet& s) { for (size_t k = 0; k < mv.size(); k++) mv[k]->adopt_storage(s[k].own, s[k].alloc, s[k].data, mv[k]->alloc_bytes); };
     auto free_set = [&](PtrSet& s) { s.clear(); };
     PtrSet best = current();
-    // A GPU that idled is still raising its clocks: step until the step time has settled (three groups of steps within 0.5 %,
-    // 1 s at most) -- otherwise the sets timed later simply look faster (seen on a cold box: the "best" set then ran 4 % slower
-    // than it had measured).  And every candidate is compared with the incumbent timed right before it, not with a number from
-    // earlier.
+    // A GPU that idled is still raising its clocks, and one that has just started to work is still heating up: at its 1400 W cap an
+    // MI355X streams 2-3 % faster in its first half second than two seconds later (round 5, profiles/r5_bench: the sets drawn read
+    // 2.889 ... 2.963 ms in the order they were timed, and the timed region of the run then 3.00).  So: step for at least 1.5 s, then
+    // until three groups of steps lie within 0.3 % (4 s at most) -- the trial numbers are then "hot" numbers, comparable with what a
+    // caller's timed region will see.  And every candidate is compared with the incumbent timed right before it, not with a number
+    // from earlier.
     {
         float g[3] = {0.f, 0.f, 0.f};
         const auto w0 = std::chrono::steady_clock::now();
-        for (int it = 0; it < 200; it++) {
+        for (int it = 0; it < 4000; it++) {
             g[it % 3] = time_steps();
             const float lo = std::min({g[0], g[1], g[2]}), hi = std::max({g[0], g[1], g[2]});
-            if (it >= 2 && lo > 0.f && hi - lo <= std::max(lo * 0.005f, 0.004f)) break;      // (short steps: 4 us of timer noise)
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() > 1.0) break;
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+            if (el > 4.0) break;
+            if (el >= 1.5 && it >= 2 && lo > 0.f && hi - lo <= std::max(lo * 0.003f, 0.004f)) break;      // (short steps: 4 us of timer noise)
         }
     }
     float best_ms = time_steps();
@@ -237,7 +240,7 @@ void Solution::run_auto_tuner_now() { tune_variants(false); }
 
 // quick: one pass with the default x-chunking, 1 warm-up + 3 timed launches per shape (used by prepare_solution() for
 // stencil libraries built by the generic registry, whose per-part defaults are a static guess).
-void Solution::tune_variants(bool quick) {
+void Solution::tune_variants(bool quick, bool fresh_storage) {
     if (!prepared) YKH_THROW("run_auto_tuner_now() called without calling prepare_solution() first");
     // events and var copies are released on every exit path (a failing launch throws)
     struct Scratch {
@@ -271,11 +274,28 @@ void Solution::tune_variants(bool quick) {
     }
     std::vector<void*>& saves = sc.saves;
     saves.assign(vars.size(), nullptr);
+    // Storage that prepare_solution() has just allocated holds zeros -- in the coefficient vars too, and a kernel that divides by zeros
+    // or streams NaNs is not the kernel the caller will run: round 5's table (profiles/r5_generic) found awp's first part on the vector
+    // point kernel where a marching shape is 16 % faster on real data.  Such storage is timed on the O(1) hashed values the placement
+    // search uses and zeroed again afterwards; storage that holds the caller's data is timed on that data (written vars saved / restored).
+    if (fresh_storage) {
+        int k = 0;
+        for (auto& v : vars) if (v->is_allocated() && !v->fixed_size) v->set_elements_hash(1.0 + 0.25 * k, 0.1, k), k++;      // (fixed-size vars are the caller's)
+    }
     for (size_t i = 0; i < vars.size(); i++)
-        if (vars[i]->is_allocated() && vars[i]->is_written) {
+        if (!fresh_storage && vars[i]->is_allocated() && vars[i]->is_written) {
             YKH_HIP(hipMalloc(&saves[i], vars[i]->bytes()));
             YKH_HIP(hipMemcpyAsync(saves[i], vars[i]->dptr, vars[i]->bytes(), hipMemcpyDeviceToDevice, compute_stream));
         }
+    // (a GPU that idled times its first candidates at rising clocks: ~30 ms of the current shapes first)
+    if (!impl.parts.empty()) {
+        const auto w0 = std::chrono::steady_clock::now();
+        do {
+            for (size_t p = 0; p < impl.parts.size(); p++)
+                if (part_variant[p] >= 0) launch_part_variant((int)p, part_variant[p], part_xchunk[p], 0, rb, compute_stream);
+            YKH_HIP(hipStreamSynchronize(compute_stream));
+        } while (std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() < 0.03);
+    }
     for (size_t p = 0; p < impl.parts.size(); p++) {
         const PartImpl& pi = impl.parts[p];
         double best = 1e30;
@@ -317,6 +337,8 @@ void Solution::tune_variants(bool quick) {
         if (saves[i]) {
             YKH_HIP(hipMemcpyAsync(vars[i]->dptr, saves[i], vars[i]->bytes(), hipMemcpyDeviceToDevice, compute_stream));
         }
+    if (fresh_storage)       // back to the zeros a fresh allocation holds
+        for (auto& v : vars) if (v->is_allocated() && !v->fixed_size) YKH_HIP(hipMemsetAsync(v->dptr, 0, std::max<size_t>(v->bytes(), 256), compute_stream));
     YKH_HIP(hipStreamSynchronize(compute_stream));
     drop_launch_plans();          // (the kernel shapes may have changed)
 }
