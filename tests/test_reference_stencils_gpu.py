@@ -86,11 +86,12 @@ def test_reference_test_stencil_matches_reference(gpu, name):
                 assert np.abs(got - ref).max() / max(1e-30, np.abs(ref).max()) <= 2e-5, (vn, key)
 
 
-def test_generic_registry_picks_spill_free_and_fast_shapes(gpu):
+def test_generic_registry_picks_fast_shapes(gpu):
     """csrc/stencil_generic.hip registers, per part, every kernel family that is legal for it; prepare_solution()
-    times them once on the real sizes and keeps the fastest shape whose kernel did not spill registers
-    (hipFuncGetAttributes localSizeBytes > 0 is never chosen).  The choice must be within 1.5x of the best
-    time measured afterwards (timing noise)."""
+    times them once on the real sizes (on hashed values when the storage is fresh: zeros in the coefficient vars would time
+    another kernel) and keeps the fastest.  The choice must be within 1.5x of the best time measured afterwards (timing
+    noise).  Since round 5 a shape whose kernel spilled registers may win that timing (awp's velocity part: +16 %); such
+    shapes are still never a STATIC default."""
     from yask_amd import yk_factory
     for stencil in ["iso3dfd_sponge", "ssg2", "test_3d", "cube", "test_boundary_3d", "awp_abc"]:
         fac = yk_factory(stencil)
@@ -100,9 +101,7 @@ def test_generic_registry_picks_spill_free_and_fast_shapes(gpu):
         for part in range(s.get_num_parts()):
             names = s.get_kernel_variant_names(part)
             chosen = s.get_kernel_variant(part)
-            assert s.get_kernel_variant_scratch_bytes(part, names.index(chosen)) == 0, (stencil, chosen)
-            times = {n: s.time_part(part=part, variant=i, t=0, reps=5) for i, n in enumerate(names)
-                     if s.get_kernel_variant_scratch_bytes(part, i) == 0}
+            times = {n: s.time_part(part=part, variant=i, t=0, reps=5) for i, n in enumerate(names)}
             assert times[chosen] <= 1.5 * min(times.values()) + 0.01, (stencil, part, chosen, times)
         if stencil == "test_boundary_3d":     # conditions that do not fill their boxes: only the point kernel is legal
             assert {s.get_kernel_variant(p) for p in range(s.get_num_parts())} == {"naive"}

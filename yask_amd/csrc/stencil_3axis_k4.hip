@@ -22,6 +22,11 @@ void s3axis_variants_k4(PartImpl& p) {
     p.variants.push_back(starlin_variant<part_1, 2, 64, 16, 1, ROT_TRIP2, 25, 4, 4>());   // + operands two planes ahead
 #endif
     p.variants.push_back(starlin_variant<part_1, 2, 32, 16, 2, ROT_UNROLL, 1 | 64, 2, 4>());   // the default shape + cheap tail planes (_tl)
+#ifdef YKH_PROFILING      // round 5 A/B: + XCD lock-step every 16 / 32 / 64 planes (512^3: x-chunks of 128 planes)
+    p.variants.push_back(starlin_variant<part_1, 2, 32, 16, 2, ROT_UNROLL, 1 | 64 | (5 << 8), 2, 4>());
+    p.variants.push_back(starlin_variant<part_1, 2, 32, 16, 2, ROT_UNROLL, 1 | 64 | (6 << 8), 2, 4>());
+    p.variants.push_back(starlin_variant<part_1, 2, 32, 16, 2, ROT_UNROLL, 1 | 64 | (7 << 8), 2, 4>());
+#endif
 #ifdef YKH_PROFILING      // (halo-late A/B, see stencil_3axis_k2.hip)
     p.variants.push_back(starlin_variant<part_1, 2, 32, 16, 2, ROT_UNROLL, 1 | 64 | 2, 2, 4>());
     p.variants.push_back(starlin_variant<part_1, 2, 32, 16, 2, ROT_UNROLL, 1 | 64 | 4, 2, 4>());

@@ -12,6 +12,10 @@ void ssg_variants_k5(PartImpl& p) {
 #endif
     p.variants.push_back(march_variant_planned<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 16>());        // exact arithmetic, trips of 2
     p.variants.push_back(march_variant_planned<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8 | 16>());
+#ifdef YKH_PROFILING      // round 5 A/B: + XCD lock-step every 16 / 64 planes (ykh_device.hpp xcd_lockstep)
+    p.variants.push_back(march_variant<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8 | 16 | (5 << 9)>());
+    p.variants.push_back(march_variant<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8 | 16 | (7 << 9)>());
+#endif
 #ifdef YKH_PROFILING      // write-through output stores: measured 1-12 % slower, profiles/r4_wt
     p.variants.push_back(march_variant<part_1, 4, 32, 16, 2, 1, false, 1, 3 | 4 | 8 | 16 | 256>());
 #endif

@@ -145,6 +145,31 @@ __device__ __forceinline__ void block_done(const PartArgs& a, int flags) {
         }
     }
 }
+// Soft LOCK-STEP of the workgroups that share an XCD (round 5; the "_ls<K>" shapes of the marching kernels).  Called at the top of every
+// loop trip (`step` planes) with d = planes marched so far: in the trip in which the block crosses a multiple of LS_K planes, thread 0
+// counts the block in at its XCD's counter (sig + 32 * (blockIdx.x % 8); an agent-scope atomic, i.e. an L2 atomic) and polls it with
+// agent-scope (sc1, L1-bypassing) loads until all gridDim.x / 8 workgroups of the XCD have arrived -- at most 400 polls, after which the
+// block stops taking part (`dead`; thread 0's copy is the one that is read).  The caller's per-plane barrier holds the other waves.
+// sig = 8 counters zeroed by the host before the launch, or null (no lock-step: Solution::launch_part_variant decides).
+// (A first version polled at workgroup scope: hipcc turned its fetch_add(0) into an sc0 LOAD, which hits the L1 and never sees the
+//  other workgroups' increments -- every wait then ran into the poll limit, profiles/r5_3axis_lockstep.)
+template <int LS_K>
+__device__ __forceinline__ void xcd_lockstep(unsigned* sig, int d, int step, bool& dead) {
+    if constexpr (LS_K > 0) {
+        const int k = d / LS_K;                      // uniform
+        if (sig && !dead && k > 0 && d - k * LS_K < step && threadIdx.x == 0) {
+            unsigned* c = sig + (blockIdx.x & 7) * 32;
+            const unsigned goal = (unsigned)k * (gridDim.x >> 3);
+            __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spin = 0;
+            for (; spin < 400; spin++) {
+                if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= goal) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (spin == 400) dead = true;
+        }
+    }
+}
 // point-kernel thread -> (x, y, z): lanes along `lane_dim`, 4 rows per block along the next outer dim, blockIdx.z
 // over what is left.  With fewer than 3 domain dims the missing ones have extent 1 (a 2-D solution used to put its 64
 // lanes on that size-1 z: 4 active lanes per 256-thread block and fully uncoalesced rows).

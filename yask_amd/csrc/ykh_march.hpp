@@ -247,6 +247,8 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
     // itself and the register is refilled right after the plane's evaluation: one copy, at the price of a shorter prefetch
     // distance (from the end of plane x to the operand's use in plane x+1).
     constexpr bool LO = (FL & 128) != 0;
+    // FL bits 9-11 ("_ls<K>", round 5): soft lock-step of the XCD's workgroups every K = 1 << (code - 1) planes (ykh_device.hpp xcd_lockstep)
+    constexpr int LS_K = ((FL >> 9) & 7) == 0 ? 0 : (1 << (((FL >> 9) & 7) - 1));
     constexpr int KT = (FL & 64) ? 8 : ((FL & 32) ? 4 : ((FL & 16) ? 2 : 1));
     static_assert(KT == 1 || KT % PD == 0, "the trip must be a multiple of the prefetch depth");
     typedef MarchCfg<P, VZ, TZL, TYL, RY, HR> C;
@@ -497,12 +499,16 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
             });
     };
     typedef std::integral_constant<int, 0> I0;
+    [[maybe_unused]] bool ls_dead = false;
     if constexpr (KT == 1) {
         // PD planes per trip; a trip may run past xe-1 (stores are predicated, loads clamped)
-        for (int x = xs; x < xe; x += PD)
+        for (int x = xs; x < xe; x += PD) {
+            if constexpr (LS_K > 0 && !DESC) xcd_lockstep<LS_K>(a.sig, x - xs, PD, ls_dead);
             static_for<PD>([&](auto sc) { plane(x + decltype(sc)::value, sc, I0{}); });
+        }
     } else {
         for (int x = xs; x < xe; x += KT) {
+            if constexpr (LS_K > 0 && !DESC) xcd_lockstep<LS_K>(a.sig, x - xs, KT, ls_dead);
             static_for<KT>([&](auto pc) {
                 constexpr int p = decltype(pc)::value;
                 plane(x + p, std::integral_constant<int, p % PD>{}, pc);

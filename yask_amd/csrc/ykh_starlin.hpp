@@ -623,30 +623,10 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::false_type NoTail;
-    // Soft lock-step of the XCD's workgroups (LS_K > 0, see above): called at the top of every loop trip (`step` planes); the trip in
-    // which the block crosses a multiple of LS_K planes counts the block in and waits.  A block that once waited in vain (poll limit:
-    // the workgroups are not all resident, or do not sit where blockIdx % 8 says) stops taking part for the rest of its range.
+    // Soft lock-step of the XCD's workgroups (LS_K > 0, see above; ykh_device.hpp xcd_lockstep): at the top of every loop trip.
     [[maybe_unused]] bool ls_dead = false;
     [[maybe_unused]] auto xcd_sync = [&](int x, int step) {
-        if constexpr (LS_K > 0 && !DESC) {
-            const int d = x - xs, k = d / LS_K;                      // uniform
-            if (a.sig && !ls_dead && k > 0 && d - k * LS_K < step) {
-                if (threadIdx.x == 0) {
-                    unsigned* c = a.sig + (blockIdx.x & 7) * 32;
-                    const unsigned goal = (unsigned)k * (gridDim.x >> 3);
-                    // (agent scope: the add is an L2 atomic, the poll an sc1 load that bypasses this CU's L1.  A first version polled at
-                    //  workgroup scope: hipcc turned its fetch_add(0) into an sc0 LOAD, which hits the L1 and never sees the other
-                    //  workgroups' increments -- every wait then ran into the poll limit, profiles/r5_3axis_lockstep)
-                    __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    int spin = 0;
-                    for (; spin < 400; spin++) {
-                        if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= goal) break;
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                    if (spin == 400) ls_dead = true;            // (thread 0's copy is the one that is read)
-                }
-            }
-        }
+        if constexpr (LS_K > 0 && !DESC) xcd_lockstep<LS_K>(a.sig, x - xs, step, ls_dead);
     };
     if constexpr (TAILOPT) {
         // _tl shapes: the main loop runs whole trips of full planes only (its code is exactly the plain shape's); what is left of

@@ -102,9 +102,11 @@ KernelVariant march_variant() {
     typedef MarchCfg<P, VZ, TZL, TYL, RY, (NT & 2) != 0> C;
     static_assert(C::lds_bytes <= 160 * 1024, "march tile does not fit the 160 KiB LDS");
     static const std::string name = "march_v" + std::to_string(VZ) + "_z" + std::to_string(C::TZ) + "_y" +
-                                    std::to_string(C::TY) + (RY > 1 ? "_r" + std::to_string(RY) : "") + (PIN ? "_pin" : "") + (PD > 1 ? "_pd" + std::to_string(PD) : "") + ((NT & 1) ? "_nt" : "") + ((NT & 2) ? "_hr" : "") + ((NT & 4) ? "_ps" : "") + ((NT & 8) ? "_fd" : "") + ((NT & 64) ? "_t8" : ((NT & 32) ? "_t4" : ((NT & 16) ? "_t2" : ""))) + ((NT & 128) ? "_lo" : "") + ((NT & 256) ? "_wt" : "") + "_w" + std::to_string(MINW);
+                                    std::to_string(C::TY) + (RY > 1 ? "_r" + std::to_string(RY) : "") + (PIN ? "_pin" : "") + (PD > 1 ? "_pd" + std::to_string(PD) : "") + ((NT & 1) ? "_nt" : "") + ((NT & 2) ? "_hr" : "") + ((NT & 4) ? "_ps" : "") + ((NT & 8) ? "_fd" : "") + ((NT & 64) ? "_t8" : ((NT & 32) ? "_t4" : ((NT & 16) ? "_t2" : ""))) + ((NT & 128) ? "_lo" : "") + ((NT & 256) ? "_wt" : "") +
+                                    (((NT >> 9) & 7) ? "_ls" + std::to_string(1 << (((NT >> 9) & 7) - 1)) : "") + "_w" + std::to_string(MINW);
     KernelVariant kv{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_march<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT>};
     kv.vz = VZ;
+    kv.lockstep = ((NT >> 9) & 7) != 0;
     kv.func = reinterpret_cast<const void*>(&march_kernel<P, VZ, TZL, TYL, MINW, RY, PIN, PD, NT>);
     kv.xover = C::XOVER;                  // a block's prologue: the deepest x queue it fills before its first plane
     return kv;
