@@ -103,8 +103,10 @@ def test_generic_registry_picks_fast_shapes(gpu):
             chosen = s.get_kernel_variant(part)
             times = {n: s.time_part(part=part, variant=i, t=0, reps=5) for i, n in enumerate(names)}
             assert times[chosen] <= 1.5 * min(times.values()) + 0.01, (stencil, part, chosen, times)
-        if stencil == "test_boundary_3d":     # conditions that do not fill their boxes: only the point kernel is legal
-            assert {s.get_kernel_variant(p) for p in range(s.get_num_parts())} == {"naive"}
+        if stencil == "test_boundary_3d":
+            # part 2's condition does not fill its bounding box: only the point kernel is legal there.  (Part 1's box is solid: any
+            # family may win its timing -- until round 5 this test passed only because the point kernel happened to win it at 128^3.)
+            assert s.get_kernel_variant(s.get_num_parts() - 1) == "naive"
     # at 256^3 the marching kernels are 3x faster than the point kernel on the 16th-order star
     fac = yk_factory("iso3dfd_sponge")
     s = fac.new_solution(fac.new_env())
