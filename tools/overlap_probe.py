@@ -39,6 +39,11 @@ SCHEDULES = [("halves: two launches in regular order, half-exchanges pipelined (
              ("planned (rounds, shell first)", "-overlap_comms -hip_planned_launch -no-hip_halves"),
              ("slabs + interior (round 2)", "-overlap_comms -no-hip_planned_launch -no-hip_halves"),
              ("whole box, then exchange", "-no-overlap_comms")]
+# the reference's wave-front tiling across ranks (-Mbt n): halos (2 x stages - 1) x wider, every rank evaluates the steps of
+# a group on shrinking boxes, ONE exchange per n steps with all neighbours of the 26-neighbourhood.  Changes the allocation (pads): these
+# get a solution of their own (--mbt).  SURVEY section 8 row f2 / BASELINE config 5: under which link does it beat plain sweeps?
+MBT_SCHEDULES = [("wave-front tiling across ranks, -Mbt 2 (one exchange per 2 steps)", "-overlap_comms -Mbt 2"),
+                 ("wave-front tiling across ranks, -Mbt 3", "-overlap_comms -Mbt 3")]
 
 
 def main():
@@ -50,6 +55,7 @@ def main():
     ap.add_argument("--tag", default="")
     ap.add_argument("--passes", type=int, default=2, help="interleaved passes over the schedules (they share one solution)")
     ap.add_argument("--fresh-solutions", action="store_true", help="one env + solution per schedule (one pass)")
+    ap.add_argument("--mbt", action="store_true", help="also the -Mbt 2 / 3 wave-front schedules, each on a solution of its own")
     ap.add_argument("--grid-study", action="store_true", help="iso3dfd: the 8-GPU rank grids of GRID_CASES instead of the default cases")
     args = ap.parse_args()
     from yask_amd import yk_factory
@@ -125,6 +131,25 @@ def main():
                 s.end_solution()
         if shared is not None:
             shared.end_solution()
+        for label, opts in (MBT_SCHEDULES if args.mbt else []):
+            try:
+                s = make(opts)
+                s.run_solution(0, 11)
+                s.get_stats()
+                n = args.steps // 6 * 6           # whole groups of 2 and of 3 steps
+                t0 = time.perf_counter()
+                s.run_solution(12, 12 + n - 1)
+                ms = (time.perf_counter() - t0) / n * 1e3
+                st = s.get_stats()
+                rec = {"tag": args.tag, "case": name, "schedule": label, "ms_per_step": round(ms, 4), "one_rank_block_ms_per_step": round(one_ms, 4),
+                       "vs_one_rank_block": round(ms / one_ms, 3), "exposed_wait_ms": round(st.get_halo_wait_secs() / n * 1e3, 4),
+                       "halo_MB_per_step": round(st.get_halo_bytes_sent() / n / 1e6, 2), "msgs_per_step": round(st.get_halo_msgs_sent() / n, 2),
+                       "rank_grid": list(nr), "rank": rank, "solution": "own"}
+                out.append(rec)
+                print(json.dumps(rec), flush=True)
+                s.end_solution()
+            except RuntimeError as ex:
+                print(json.dumps({"case": name, "schedule": label, "error": str(ex)[:300]}), flush=True)
     od = Path(__file__).resolve().parents[1] / "gpurun_out"
     od.mkdir(exist_ok=True)
     json.dump(out, open(od / f"overlap_probe_{args.stencil}{args.tag}.json", "w"), indent=1)
