@@ -89,7 +89,8 @@ def markdown(recs, title):
            "`frac` = compulsory HBM bytes per step / step time / 8 TB/s (compulsory = distinct full-dimensional arrays read + written x element",
            "size, per part, over the part's own box; scratch vars and lower-dimensional coefficient arrays count 0).  Step time = median of",
            "per-step HIP events, default options; `families` = kernel family of every part (`starlin` / `march` = marching kernels with a",
-           "register x-queue, `star25d` = 2.5-D LDS slab, `vecpt` = 16-byte vector point kernel, `naive` = one point per thread).", "",
+           "register x-queue, `box` = marching kernel with an LDS ring of planes (box / plane neighbourhoods), `star25d` = 2.5-D LDS slab,",
+           "`vecpt` = 16-byte vector point kernel, `naive` = one point per thread).", "",
            "| solution | size | parts | step ms | Gpoints/s | compulsory GB/s | frac | families | worst part (frac) |",
            "|---|---|---|---|---|---|---|---|---|"]
     for r in recs:

@@ -1,6 +1,7 @@
 // stencil_generic.hip -- kernel registry for ANY solution the `cdna4_hip` compiler target can render.
 // Every part gets the always-legal point kernel; 3-D parts without sub-domain conditions also get, when
-// eligible (decided at compile time from the generated part): the vector-per-thread kernel, the generic
+// eligible (decided at compile time from the generated part): the vector-per-thread kernel, the plane-ring kernel
+// (ykh_box.hpp: parts with many mixed-offset reads), the generic
 // marching kernel (all offset-read and written groups are full-dim vars, slabs fit the LDS, <= 48 groups) and
 // the linear-star kernel (the compiler found the linear star form).  Default = the most specialised one.
 // Compiled once per stencil with -DYKH_GEN_HEADER="gen/<name>_cdna4_hip.hpp" -DYKH_GEN_NS=ykh_gen_<name>
@@ -59,6 +60,23 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
                     p.default_variant = (int)p.variants.size() - 1;
                     p.variants.push_back(march_variant<P, VZ, 32, 16, 2, 1, false, 1, 3 | 4>());
                 }
+            }
+            // box / plane neighbourhoods (more mixed-offset reads than the marching kernel prefetches): planes in an LDS ring
+            // (ykh_box.hpp), for as many groups as the budget holds -- registered where the rings serve at least half of the reads.
+            // Tile 128 x 16 points (fp32; 16-byte lanes): 512 threads with one row each, or 256 threads with two rows each evaluated as one
+            // wide vector (shared LDS rows are loaded once; needs ~230 VGPRs); _p2 = planes requested two iterations ahead; _w1 = one
+            // wave per SIMD with the whole register file, for parts like tti (340 VGPRs on any kernel).  prepare_solution() times them.
+            if constexpr (box_eligible<P>() && count_mixed<P>() > MAX_MIXED) {
+                constexpr int TZL = 32;          // (z tile = 32 lanes of 16 bytes)
+                if constexpr (2 * BoxCfg<P, VZ, TZL, 16, 1>::ring_reads() >= P::n_reads) {
+                    p.variants.push_back(box_variant<P, VZ, TZL, 16, 1, 2, 1>());
+                    p.default_variant = (int)p.variants.size() - 1;
+                    p.variants.push_back(box_variant<P, VZ, TZL, 16, 1, 2, 1 | 4>());
+                    p.variants.push_back(box_variant<P, VZ, TZL, 8, 2, 2, 1>());
+                    p.variants.push_back(box_variant<P, VZ, TZL, 8, 2, 2, 1 | 4>());
+                }
+                if constexpr (2 * BoxCfg<P, VZ, TZL, 8, 1, 80>::ring_reads() >= P::n_reads && P::n_reads > 130)
+                    p.variants.push_back(box_variant<P, VZ, TZL, 8, 1, 1, 1 | 4, 80>());
             }
             if constexpr (starlin_eligible<P>()) {
                 p.variants.push_back(starlin_variant<P, VZ, 32, 16, 1, ROT_MOVE, 1, 2, 4>());
