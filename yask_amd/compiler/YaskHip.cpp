@@ -96,6 +96,8 @@ namespace yask {
             const DimCtx& dc;
             vector<Group> groups;            // access groups of the part being emitted
             vector<Off> reads;               // distinct reads
+            vector<unsigned long long> read_wmask;   // per read: bit k = equation k of the part (the one that writes writes[k]) uses it
+            int cur_eq = 0;                  // equation being visited
             vector<int> writes;              // groups written
             ostringstream body;              // statements
             map<string, string> memo;        // expr string -> temp name
@@ -113,9 +115,13 @@ namespace yask {
                 return (int)groups.size() - 1;
             }
             void note_read(int g, const int* o) {
-                for (auto& r : reads)
-                    if (r.g == g && r.d[0] == o[0] && r.d[1] == o[1] && r.d[2] == o[2]) return;
+                const unsigned long long bit = cur_eq < 64 ? 1ull << cur_eq : 0ull;
+                for (size_t i = 0; i < reads.size(); i++) {
+                    auto& r = reads[i];
+                    if (r.g == g && r.d[0] == o[0] && r.d[1] == o[1] && r.d[2] == o[2]) { read_wmask[i] |= bit; return; }
+                }
                 reads.push_back(Off{g, {o[0], o[1], o[2]}});
+                read_wmask.push_back(bit);
             }
             string temp(const string& key, const string& rhs) {
                 auto it = memo.find(key);
@@ -183,6 +189,7 @@ namespace yask {
             string visit(BinaryNum2BoolExpr*) override { return fail("boolean expression in a value"); }
             string visit(BinaryBoolExpr*) override { return fail("boolean expression in a value"); }
             string visit(EqualsExpr* ee) override {
+                cur_eq = (int)writes.size();         // (every equation of a part writes another group: its index in writes[])
                 string rhs = ee->_get_rhs()->accept(this);
                 Group g; int o[3];
                 VarPoint* lhs = ee->_get_lhs().get();
@@ -544,6 +551,15 @@ namespace yask {
                 }
                 if (em.reads.empty()) os << "{0, 0, 0, 0}";
                 os << "};\n";
+                // which equations use each read (bit k = the equation that writes writes[k]): lets the runtime evaluate a part as
+                // several clusters of its equations, each a kernel over the reads it needs (csrc/ykh_subpart.hpp)
+                if (em.writes.size() > 1 && em.writes.size() <= 64) {
+                    os << "    static constexpr unsigned long long read_wmask[" << (em.reads.size() ? em.reads.size() : 1) << "] = {";
+                    for (size_t i = 0; i < em.reads.size(); i++)
+                        os << (i % 12 == 0 ? "\n        " : " ") << "0x" << hex << em.read_wmask[i] << dec << "ull" << (i + 1 < em.reads.size() ? "," : "");
+                    if (em.reads.empty()) os << "0ull";
+                    os << "};\n";
+                }
                 os << "    static constexpr int n_writes = " << em.writes.size() << ";\n"
                       "    static constexpr int writes[" << em.writes.size() << "] = {";
                 for (size_t i = 0; i < em.writes.size(); i++) os << (i ? ", " : "") << em.writes[i];

@@ -78,6 +78,17 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
                 if constexpr (2 * BoxCfg<P, VZ, TZL, 8, 1, 80>::ring_reads() >= P::n_reads && P::n_reads > 130)
                     p.variants.push_back(box_variant<P, VZ, TZL, 8, 1, 1, 1 | 4, 80>());
             }
+            // big bundles (fsg: 12 and 24 equations, 296 / 435 reads): the part as K clusters of equations, one launch each
+            // (ykh_subpart.hpp) -- on the point kernel (a cluster needs a third of the registers: three waves per SIMD instead
+            // of one) and, where every cluster's slabs fit the LDS, on the marching kernel.
+            if constexpr (P::n_writes >= 12) {
+                if constexpr (clusters_legal<P, 4>()) {
+                    p.variants.push_back(vecpt_cluster_variant<P, 4, VZ, 64, 4, 1>());
+                    if constexpr (march_clusters_fit<P, 4, 2, 64, 8, 0>()) p.variants.push_back(march_cluster_variant<P, 4, 2, 64, 8, 2, 0>());
+                }
+                if constexpr (clusters_legal<P, 2>()) p.variants.push_back(vecpt_cluster_variant<P, 2, VZ, 64, 4, 1>());
+                if constexpr (P::n_writes >= 24 && clusters_legal<P, 8>()) p.variants.push_back(vecpt_cluster_variant<P, 8, VZ, 64, 4, 1>());
+            }
             if constexpr (starlin_eligible<P>()) {
                 p.variants.push_back(starlin_variant<P, VZ, 32, 16, 1, ROT_MOVE, 1, 2, 4>());
                 p.default_variant = (int)p.variants.size() - 1;

@@ -10,6 +10,7 @@
 #include "ykh_vecpt.hpp"
 #include "ykh_march.hpp"
 #include "ykh_box.hpp"
+#include "ykh_subpart.hpp"
 #include "ykh_runtime.hpp"
 
 namespace ykh {
@@ -145,6 +146,59 @@ KernelVariant box_variant() {
     kv.vz = VZ;
     kv.func = reinterpret_cast<const void*>(&box_kernel<P, VZ, TZL, TYL, RY, MINW, FL, LDS_KB>);
     kv.xover = C::XOVER;
+    return kv;
+}
+
+// ---- a part as K clusters of its equations, one launch each (ykh_subpart.hpp).  The runtime sees ONE variant whose launch function
+// issues the K kernels back to back on the stream (same tile shape, same grid, same PartArgs: a cluster's kernel touches only the
+// groups its equations use).  Name: c<K>_<name of the shape the clusters run on>.
+template <class P, int K, int VZ, int TZL, int TYL, int RX, int... C>
+void launch_vecpt_clusters_(const PartArgs& a, dim3 grid, hipStream_t s, std::integer_sequence<int, C...>) {
+    (launch_vecpt<SubPart<P, cluster_mask<P, K>(C)>, VZ, TZL, TYL, RX>(a, grid, s), ...);
+}
+template <class P, int K, int VZ, int TZL, int TYL, int RX>
+void launch_vecpt_clusters(const PartArgs& a, dim3 grid, hipStream_t s) {
+    launch_vecpt_clusters_<P, K, VZ, TZL, TYL, RX>(a, grid, s, std::make_integer_sequence<int, K>{});
+}
+template <class P, int K, int VZ, int TZL, int TYL, int RX>
+KernelVariant vecpt_cluster_variant() {
+    typedef SubPart<P, cluster_mask<P, K>(0)> S0;
+    KernelVariant kv = vecpt_variant<S0, VZ, TZL, TYL, RX>();
+    static const std::string name = "c" + std::to_string(K) + "_" + kv.name;
+    kv.name = name.c_str();
+    kv.launch = &launch_vecpt_clusters<P, K, VZ, TZL, TYL, RX>;
+    return kv;
+}
+template <class P, int K, int VZ, int TZL, int TYL, int MINW, int NT, int... C>
+void launch_march_clusters_(const PartArgs& a, dim3 grid, hipStream_t s, std::integer_sequence<int, C...>) {
+    (launch_march<SubPart<P, cluster_mask<P, K>(C)>, VZ, TZL, TYL, MINW, 1, false, 1, NT>(a, grid, s), ...);
+}
+template <class P, int K, int VZ, int TZL, int TYL, int MINW, int NT>
+void launch_march_clusters(const PartArgs& a, dim3 grid, hipStream_t s) {
+    launch_march_clusters_<P, K, VZ, TZL, TYL, MINW, NT>(a, grid, s, std::make_integer_sequence<int, K>{});
+}
+// every cluster of the part fits the marching kernel at this tile (eligible, slabs within the LDS)
+template <class P, int K, int VZ, int TZL, int TYL, int NT, int... C>
+constexpr bool march_clusters_fit_(std::integer_sequence<int, C...>) {
+    return ((march_eligible<SubPart<P, cluster_mask<P, K>(C)>>() &&
+             MarchCfg<SubPart<P, cluster_mask<P, K>(C)>, VZ, TZL, TYL, 1, (NT & 2) != 0>::lds_bytes <= 160 * 1024) && ...);
+}
+template <class P, int K, int VZ, int TZL, int TYL, int NT>
+constexpr bool march_clusters_fit() { return march_clusters_fit_<P, K, VZ, TZL, TYL, NT>(std::make_integer_sequence<int, K>{}); }
+template <class P, int K, int VZ, int TZL, int TYL, int NT, int... C>
+constexpr size_t march_clusters_lds_(std::integer_sequence<int, C...>) {
+    size_t m = 0;
+    ((m = MarchCfg<SubPart<P, cluster_mask<P, K>(C)>, VZ, TZL, TYL, 1, (NT & 2) != 0>::lds_bytes > m ? MarchCfg<SubPart<P, cluster_mask<P, K>(C)>, VZ, TZL, TYL, 1, (NT & 2) != 0>::lds_bytes : m), ...);
+    return m;
+}
+template <class P, int K, int VZ, int TZL, int TYL, int MINW, int NT>
+KernelVariant march_cluster_variant() {
+    typedef SubPart<P, cluster_mask<P, K>(0)> S0;
+    KernelVariant kv = march_variant<S0, VZ, TZL, TYL, MINW, 1, false, 1, NT>();
+    static const std::string name = "c" + std::to_string(K) + "_" + kv.name;
+    kv.name = name.c_str();
+    kv.launch = &launch_march_clusters<P, K, VZ, TZL, TYL, MINW, NT>;
+    kv.lds_bytes = march_clusters_lds_<P, K, VZ, TZL, TYL, NT>(std::make_integer_sequence<int, K>{});
     return kv;
 }
 
