@@ -59,7 +59,7 @@ def test_unknown_target_still_throws(tmp_path):
     assert "YASK error" in r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("name,extra", [("iso3dfd", ()), ("ssg", ()), ("awp_abc", ()), ("swe2d", ()), ("test_step_cond_1d", ()), ("test_4d", ())])
+@pytest.mark.parametrize("name,extra", [("iso3dfd", ()), ("ssg", ()), ("awp_abc", ()), ("swe2d", ()), ("test_step_cond_1d", ()), ("test_4d", ()), ("fsg", ()), ("tti", ())])
 def test_committed_headers_are_what_the_target_emits(tmp_path, name, extra):
     """yask_amd/csrc/gen/<name>_cdna4_hip.hpp is the unedited output of the target (the kernel libraries are built
     from it)."""
@@ -115,3 +115,34 @@ def test_subtraction_division_and_step_value_contract():
             tail = row.rstrip("}").split("::step_cond,")[1].split(",")
             assert (len(tail) == 2 and tail[1].strip() == "true") == w, (name, row)
     assert any(len(r.rstrip("}").split("::step_cond,")[1].split(",")) == 2 for r in part_rows("swe2d"))
+
+
+def test_read_masks_say_which_equations_use_each_read():
+    """`read_wmask[i]` (parts with several equations): bit k = the equation that writes `writes[k]` uses read i.  The runtime
+    evaluates big bundles as clusters of equations from it (csrc/ykh_subpart.hpp: the reads of a cluster, and the compile-time
+    check that no cluster reads what another one writes).  Checked here against the equations as the header quotes them in its
+    comments (the reference front-end's own rendering, `Expr::make_str`): the vars an equation names on its right-hand side are
+    exactly the vars of the reads that carry its bit, and the number of distinct points it reads there is the number of such reads."""
+    for soln, pname, nxt in (("ssg", "part_1", "part_2"), ("fsg", "part_2", None), ("tti", "part_1", None)):
+        txt = (GEN / f"{soln}_cdna4_hip.hpp").read_text()
+        head = txt[:txt.index(f"struct {pname} {{")]
+        part = txt[txt.index(f"struct {pname} {{"):]
+        if nxt:
+            part = part[:part.index(f"struct {nxt} {{")]
+        eqs = [l[5:] for l in head[head.rindex("// ////// Stencil part"):].splitlines()[1:] if l.startswith("//   ")]
+        reads = [tuple(int(x) for x in m) for m in re.findall(r"\{(\d+), (-?\d+), (-?\d+), (-?\d+)\}", part[part.index("ReadOff reads"):part.index("read_wmask")])]
+        masks = [int(x, 16) for x in re.findall(r"0x([0-9a-f]+)ull", part[part.index("read_wmask"):part.index("n_writes")])]
+        writes = [int(x) for x in re.search(r"int writes\[\d+\] = \{([^}]*)\}", part).group(1).split(",")]
+        name = {int(g): n for g, n in re.findall(r"// g(\d+): (\w+)", part)}
+        assert len(reads) == len(masks) and len(eqs) == len(writes) > 1, (soln, len(reads), len(masks), len(eqs), len(writes))
+        assert all(0 < m < (1 << len(writes)) for m in masks)
+        for k, (w, eq) in enumerate(zip(writes, eqs)):
+            lhs, rhs = eq.split(" EQUALS ", 1)
+            assert lhs.startswith(name[w] + "("), (soln, k, lhs[:40], name[w])
+            points = set(re.findall(r"(\w+)\(([^()]*(?:\([^()]*\)[^()]*)*)\)", rhs))       # var(index expressions)
+            points = {(v, idx) for v, idx in points if v in name.values()}
+            mine = [name[r[0]] for r, m in zip(reads, masks) if (m >> k) & 1]
+            assert set(mine) == {v for v, _ in points}, (soln, k, sorted(set(mine) ^ {v for v, _ in points}))
+            assert len(mine) == len(points), (soln, k, len(mine), len(points))
+    # one-equation parts carry no table
+    assert "read_wmask" not in (GEN / "iso3dfd_cdna4_hip.hpp").read_text()

@@ -77,6 +77,12 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
                 }
                 if constexpr (2 * BoxCfg<P, VZ, TZL, 8, 1, 80>::ring_reads() >= P::n_reads && P::n_reads > 130)
                     p.variants.push_back(box_variant<P, VZ, TZL, 8, 1, 1, 1 | 4, 80>());
+                // where the 128 x 16 tile leaves groups without a ring, the half-height tile holds more of them in the same LDS
+                if constexpr (BoxCfg<P, VZ, TZL, 8, 1>::ring_reads() > BoxCfg<P, VZ, TZL, 16, 1>::ring_reads() &&
+                              2 * BoxCfg<P, VZ, TZL, 8, 1>::ring_reads() >= P::n_reads) {
+                    p.variants.push_back(box_variant<P, VZ, TZL, 8, 1, 2, 1 | 4>());
+                    if constexpr (P::n_reads > 130) p.variants.push_back(box_variant<P, VZ, TZL, 8, 1, 1, 1 | 4>());
+                }
             }
             // big bundles (fsg: 12 and 24 equations, 296 / 435 reads): the part as K clusters of equations, one launch each
             // (ykh_subpart.hpp) -- on the point kernel (a cluster needs a third of the registers: three waves per SIMD instead
@@ -93,6 +99,10 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
                 p.variants.push_back(starlin_variant<P, VZ, 32, 16, 1, ROT_MOVE, 1, 2, 4>());
                 p.default_variant = (int)p.variants.size() - 1;
                 p.variants.push_back(starlin_variant<P, VZ, 32, 16, 2, ROT_MOVE, 1, 2, 4>());
+                // the shape that won iso3dfd's sweeps (2-plane trips with queue renaming, star planes two ahead, cheap tail planes,
+                // LDS batches of 2; stencil_iso3dfd_k4.hip): any fp32 star with an x range gets it as a candidate for the timing
+                // (iso3dfd_sponge: the same star + three 1-D sponge profiles)
+                if constexpr (VZ == 4 && lin_range<P>().xhi > 0) p.variants.push_back(starlin_variant<P, VZ, 32, 16, 2, ROT_TRIP2, 9 | 64, 2, 2>());
             }
         }
     }

@@ -360,6 +360,9 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
                 } else {
                     // var over a subset of the domain dims (e.g. the 1-D sponge coefficients of iso3dfd_sponge):
                     // own strides (0 for a missing dim); without the unit-stride dim the value is broadcast
+                    // (operands without the marching dim -- iso3dfd_sponge's y and z profiles -- were loaded once, before the loop:
+                    //  round 5; they used to be re-loaded every plane, two rows of 64-bit address arithmetic and a load each)
+                    if (a.gsx[g] != 0) {
                     const int xg = (int)((pc - org) / a.sx);      // plane index (uniform)
                     static_for<RY>([&](auto jc) {
                         constexpr int j = decltype(jc)::value;
@@ -368,10 +371,28 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
                         if (a.gsz[g] == 0) cen[CS][g][j] = V(gp[0]);
                         else cen[CS][g][j] = ldv<V>(gp + zc);
                     });
+                    }
                 }
             }
         });
     };
+    // partial-dim operands that do not depend on x: every operand set, once
+    static_for<CD>([&](auto cs) {
+        constexpr int CS = decltype(cs)::value;
+        static_for<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g != SG && analyze_group<P>(g).any && !P::group_full[g]) {
+                if (a.gsx[g] == 0)
+                    static_for<RY>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        const int y = clampi(yt0 + ly * RY + j, a.ay0, a.ay1 - 1);
+                        const T* gp = (const T*)a.ptr[g] + (idx_t)y * a.gsy[g];
+                        if (a.gsz[g] == 0) cen[CS][g][j] = V(gp[0]);
+                        else cen[CS][g][j] = ldv<V>(gp + zc);
+                    });
+            }
+        });
+    });
     auto load_interior = [&](int x, auto sc) {
         constexpr int S = decltype(sc)::value;
         auto pp = sbase(sp + xplane(x));
