@@ -263,6 +263,13 @@ yk_idx_t yk_solution_get_kernel_variant_scratch_bytes(yk_soln_h s, int part, int
  * such a box, 0 if it is unconditional (first/last = the rank's domain), 2 if the condition holds nowhere in this
  * rank (first > last), -1 on error. */
 int yk_solution_get_part_bounding_box(yk_soln_h s, int part, yk_idx_t* first, yk_idx_t* last);
+/* The list of FULL boxes of part `part`'s sub-domain condition in this rank: non-overlapping rectangles that hold valid points
+ * only and together all of them -- the reference's StencilPartBase::_bb_list (src/kernel/lib/setup.cpp:1235-1500), which its
+ * kernels walk box by box.  prepare_solution() finds it (two device reductions, no per-point mask) where the condition does not
+ * fill its bounding box but is a handful of slabs; the part then runs its unpredicated kernels on each box.  Fills up to `cap`
+ * boxes (3 rank-local indices each in first / last, last inclusive) and returns their number: 0 = no list (unconditional part,
+ * a condition that fills its bounding box, or one left to the point kernel's per-point predicate), -1 on error. */
+int yk_solution_get_part_full_boxes(yk_soln_h s, int part, int cap, yk_idx_t* first, yk_idx_t* last);
 /* Work of one stencil part, per step on this rank -- the facts the reference prints per part and stage in
  * Stage::init_work_stats (src/kernel/lib/stencil_calc.cpp:461-598: points to eval, reads / writes / est FP-ops per point, the
  * input / output var lists), plus what a bandwidth-bound GPU kernel is measured against: the COMPULSORY HBM bytes per point =

@@ -30,7 +30,7 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
     PartImpl p;
     p.meta = meta;
     p.variants.push_back(naive_variant<P>());
-    if constexpr (P::has_domain_cond) p.cond_bb = &launch_cond_bb<P>;
+    if constexpr (P::has_domain_cond) { p.cond_bb = &launch_cond_bb<P>; p.cond_profile = &launch_cond_profile<P>; }
     // Sub-domain parts get the same kernels: they do not evaluate the condition, and prepare_solution() selects
     // them only when the condition holds at every point of its bounding box (a "solid" box, e.g. awp's
     // below-the-surface updates); otherwise the point kernel runs.

@@ -425,6 +425,18 @@ int yk_solution_get_part_bounding_box(yk_soln_h s, int part, yk_idx_t* first, yk
     return !has ? 0 : (b.empty() ? 2 : 1);
     YK_CATCH(-1)
 }
+int yk_solution_get_part_full_boxes(yk_soln_h s, int part, int cap, yk_idx_t* first, yk_idx_t* last) {
+    YK_TRY
+    Solution& so = S(s);
+    if (part < 0 || part >= (int)so.impl.parts.size()) YKH_THROW("part index out of range");
+    if (!so.prepared) YKH_THROW("get_part_full_boxes() called without calling prepare_solution() first");
+    if ((size_t)part >= so.part_boxes.size()) return 0;
+    const auto& bl = so.part_boxes[part];
+    for (int i = 0; i < (int)bl.size() && i < cap; i++)
+        for (int d = 0; d < 3; d++) { first[3 * i + d] = bl[i].lo[d]; last[3 * i + d] = bl[i].hi[d] - 1; }
+    return (int)bl.size();
+    YK_CATCH(-1)
+}
 int yk_solution_get_part_info(yk_soln_h s, int part, yk_part_info_t* out) {
     YK_TRY
     Solution& so = S(s);
@@ -451,6 +463,10 @@ int yk_solution_get_part_info(yk_soln_h s, int part, yk_part_info_t* out) {
     const Box b = has ? so.part_bb[part] : so.rank_box();
     yk_idx_t pts = b.empty() ? 0 : 1;
     for (int d = 0; d < so.ndd && pts; d++) pts *= b.hi[d] - b.lo[d];
+    if ((size_t)part < so.part_boxes.size() && !so.part_boxes[part].empty()) {      // the valid points, not their bounding box
+        pts = 0;
+        for (const Box& fb : so.part_boxes[part]) { yk_idx_t v = 1; for (int d = 0; d < so.ndd; d++) v *= fb.hi[d] - fb.lo[d]; pts += v; }
+    }
     if (so.has_outer) pts *= so.local_size[3];
     out->points = pts;
     out->compulsory_bytes_per_point = (double)(out->arrays_read + out->arrays_written) * so.elem_bytes();

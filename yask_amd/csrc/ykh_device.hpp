@@ -324,6 +324,34 @@ __global__ void __launch_bounds__(256) cond_bb_kernel(const PartArgs a, int* out
     }
 }
 
+// Per-index counts of the points of a box where the condition holds, along each domain dim: hist[0 .. nx) for x, then ny entries
+// for y, then nz for z (zeroed by the caller; 3-D solutions, lanes along z).  A profile is piecewise constant between the planes
+// that bound the condition's region: prepare_solution() cuts the bounding box there and ends up with the reference's list of FULL
+// bounding boxes (non-overlapping, valid points only; StencilPartBase::find_bounding_boxes, src/kernel/lib/setup.cpp:1235-1500)
+// without ever holding a per-point mask.
+template <class P>
+__global__ void __launch_bounds__(256) cond_profile_kernel(const PartArgs a, unsigned* hist) {
+    __shared__ unsigned hz[64], hy[4], hx;
+    if (threadIdx.x < 64) hz[threadIdx.x] = 0;
+    if (threadIdx.x < 4) hy[threadIdx.x] = 0;
+    if (threadIdx.x == 0) hx = 0;
+    __syncthreads();
+    const PointXYZ q = point_of_thread(a);
+    bool on = false;
+    if constexpr (P::has_domain_cond) {
+        if (q.z < a.z1 && q.y < a.y1 && q.x < a.x1) {
+            NaiveAcc<P> acc{a, q.x, q.y, q.z, 0};
+            on = P::cond(acc);
+        }
+    }
+    if (on) { atomicAdd(&hz[threadIdx.x & 63], 1u); atomicAdd(&hy[threadIdx.x >> 6], 1u); atomicAdd(&hx, 1u); }
+    __syncthreads();
+    const int nx = a.x1 - a.x0, ny = a.y1 - a.y0;
+    if (threadIdx.x < 64 && hz[threadIdx.x]) atomicAdd(&hist[nx + ny + blockIdx.x * 64 + threadIdx.x], hz[threadIdx.x]);
+    if (threadIdx.x < 4 && hy[threadIdx.x]) atomicAdd(&hist[nx + blockIdx.y * 4 + threadIdx.x], hy[threadIdx.x]);
+    if (threadIdx.x == 0 && hx) atomicAdd(&hist[blockIdx.z], hx);
+}
+
 // ------------------------------------------------------------------ star25d kernel
 enum { ROT_MOVE = 0, ROT_UNROLL = 1, ROT_TRIP = 2, ROT_TRIP2 = 3 };   // (the last two: starlin only, see ykh_starlin.hpp)
 

@@ -78,6 +78,8 @@ struct PartImpl {
     int large_grid_variant = -1;       // preferred over the default when its (y,z) tiles alone cover at least half of the CUs
     // sub-domain (IF_DOMAIN) parts: launches cond_bb_kernel over the box of `a` (grid as for the naive kernel)
     void (*cond_bb)(const PartArgs& a, dim3 grid, int* dev_out, hipStream_t s) = nullptr;
+    // ... and cond_profile_kernel: per-index counts along x, y, z of the box (3-D solutions)
+    void (*cond_profile)(const PartArgs& a, dim3 grid, unsigned* dev_hist, hipStream_t s) = nullptr;
     void set_default(const char* name) {
         for (size_t i = 0; i < variants.size(); i++)
             if (std::string(variants[i].name) == name) { default_variant = (int)i; return; }
@@ -400,10 +402,17 @@ public:
     std::vector<int> part_variant;                   // chosen variant per part
     std::vector<Box> part_bb;                        // sub-domain parts: bounding box of the condition (local indices)
     std::vector<char> part_has_bb, part_bb_solid;    // solid: the condition holds everywhere in the box
+    // sub-domain parts whose condition does not fill its bounding box: the reference's list of FULL bounding boxes (non-overlapping,
+    // valid points only: StencilPartBase::_bb_list, setup.cpp:1235-1500) where prepare_solution() found one (find_part_boxes);
+    // the part then runs its unpredicated kernels box by box.  Empty: the point kernel evaluates the condition per point.
+    std::vector<std::vector<Box>> part_boxes;
+    bool in_part_boxes_ = false;                     // launch_part_variant is walking a part's box list
+    bool find_part_boxes(int part, const Box& bb, unsigned long long count, std::vector<Box>& out);
     bool part_needs_predicate(int part) const {      // only the point kernel evaluates the condition per point
         const PartMeta& pm = *impl.parts[part].meta;
         if (pm.has_step_cond_dev) return true;
         if (!pm.has_domain_cond) return false;
+        if ((size_t)part < part_boxes.size() && !part_boxes[part].empty()) return false;
         return !((size_t)part < part_has_bb.size() && part_has_bb[part] && part_bb_solid[part]);
     }
     std::vector<idx_t> part_xchunk;

@@ -496,6 +496,7 @@ void Solution::prepare() {
     part_bb.assign(impl.parts.size(), rank_box());
     part_has_bb.assign(impl.parts.size(), 0);
     part_bb_solid.assign(impl.parts.size(), 0);
+    part_boxes.assign(impl.parts.size(), std::vector<Box>());
     {
         int* dbb = nullptr;
         for (size_t p = 0; p < impl.parts.size(); p++) {
@@ -534,6 +535,13 @@ void Solution::prepare() {
             unsigned long long vol = 1;
             for (int d = 0; d < MAX_DOMAIN_DIMS; d++) vol *= (unsigned long long)std::max<idx_t>(0, bb.hi[d] - bb.lo[d]);
             part_bb_solid[p] = (count == vol);     // the condition holds at every point of the box
+            // not solid: the list of full boxes, when the region is a handful of them (awp's free-surface planes minus their
+            // sponge margins, fsg_abc's 20-point shell = 6 boxes); the fast kernels then run box by box instead of the point
+            // kernel sweeping the bounding box with a predicate (fsg_abc 512^3: 30 ms for the stress part's shell)
+            if (!part_bb_solid[p] && count > 0 && ndd == 3 && !has_outer && !wf_multi() && pi.cond_profile) {
+                std::vector<Box> boxes;
+                if (find_part_boxes((int)p, bb, count, boxes)) part_boxes[p] = std::move(boxes);
+            }
         }
         if (dbb) YKH_HIP(hipFree(dbb));
     }
@@ -653,6 +661,98 @@ void Solution::end() {
     prepared = false;
 }
 
+// ------------------------------------------------------------------ full boxes of a sub-domain condition
+// The reference turns a sub-domain condition into a list of FULL bounding boxes -- non-overlapping rectangles holding valid points
+// only -- by scanning every point on the host (StencilPartBase::find_bounding_boxes, src/kernel/lib/setup.cpp:1235-1500: slices per
+// thread, rectangles grown point by point, merged afterwards).  Here the condition is device code and the grid may hold 2^30
+// points: two reductions do the work.  cond_bb_kernel gives the bounding box and the number of valid points of a query box
+// (count == volume: the box is full); cond_profile_kernel gives the number of valid points per index along x, y and z.  A profile
+// is constant between the planes that bound the region, so a box that is not full is cut at the breakpoints of the dim with the
+// fewest of them and the pieces are examined again.  Regions made of a few slabs (a shell of fixed width: 6 boxes) resolve in
+// three levels; anything that does not -- a slanted or scattered condition -- is left to the point kernel's per-point predicate
+// (returns false; limits: 8 pieces per cut, 64 boxes, 8 levels).  Exact by construction and checked: every emitted box is full
+// and the volumes add up to the number of valid points.
+bool Solution::find_part_boxes(int part, const Box& bb0, unsigned long long total, std::vector<Box>& out) {
+    const PartImpl& pi = impl.parts[part];
+    int* dbb = nullptr;
+    unsigned* dhist = nullptr;
+    YKH_HIP(hipMalloc(&dbb, 8 * sizeof(int)));
+    struct Free { int* a; unsigned*& b; ~Free() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } guard{dbb, dhist};
+    auto volume = [&](const Box& b) { unsigned long long v = 1; for (int d = 0; d < 3; d++) v *= (unsigned long long)std::max<idx_t>(0, b.hi[d] - b.lo[d]); return v; };
+    auto query = [&](const Box& q, Box& bb) -> unsigned long long {
+        const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
+        YKH_HIP(hipMemcpyAsync(dbb, init, sizeof(init), hipMemcpyHostToDevice, compute_stream));
+        PartArgs a;
+        fill_part_args(part, 0, q, a);
+        pi.cond_bb(a, point_grid(q, a.lane_dim), dbb, compute_stream);
+        YKH_HIP(hipGetLastError());
+        int o[8];
+        YKH_HIP(hipMemcpyAsync(o, dbb, sizeof(o), hipMemcpyDeviceToHost, compute_stream));
+        YKH_HIP(hipStreamSynchronize(compute_stream));
+        unsigned long long c;
+        std::memcpy(&c, &o[6], sizeof(c));
+        bb = q;
+        if (c) for (int d = 0; d < 3; d++) { bb.lo[d] = o[d]; bb.hi[d] = o[3 + d] + 1; }
+        return c;
+    };
+    size_t hist_cap = 0;
+    std::vector<unsigned> hist;
+    struct Item { Box b; int depth; bool known; unsigned long long count; };
+    std::vector<Item> todo{{bb0, 0, true, total}};
+    unsigned long long covered = 0;
+    while (!todo.empty()) {
+        Item it = todo.back();
+        todo.pop_back();
+        Box bb = it.b;
+        const unsigned long long c = it.known ? it.count : query(it.b, bb);
+        if (c == 0) continue;
+        if (c == volume(bb)) {
+            out.push_back(bb);
+            covered += c;
+            if (out.size() > 64) return false;
+            continue;
+        }
+        if (it.depth >= 8) return false;
+        PartArgs a;
+        fill_part_args(part, 0, bb, a);
+        if (a.lane_dim != 2) return false;
+        const idx_t n[3] = {bb.hi[0] - bb.lo[0], bb.hi[1] - bb.lo[1], bb.hi[2] - bb.lo[2]};
+        const size_t need = (size_t)(n[0] + n[1] + n[2]) + 64 + 4;      // (blocks cover 64 z / 4 y: counts of the overhang are zero)
+        if (need > hist_cap) {
+            if (dhist) (void)hipFree(dhist);
+            dhist = nullptr;
+            YKH_HIP(hipMalloc(&dhist, need * sizeof(unsigned)));
+            hist_cap = need;
+        }
+        YKH_HIP(hipMemsetAsync(dhist, 0, need * sizeof(unsigned), compute_stream));
+        pi.cond_profile(a, point_grid(bb, a.lane_dim), dhist, compute_stream);
+        YKH_HIP(hipGetLastError());
+        hist.resize(need);
+        YKH_HIP(hipMemcpyAsync(hist.data(), dhist, need * sizeof(unsigned), hipMemcpyDeviceToHost, compute_stream));
+        YKH_HIP(hipStreamSynchronize(compute_stream));
+        // breakpoints per dim; cut along the dim with the fewest pieces (> 1)
+        int best = -1;
+        std::vector<idx_t> cuts[3];
+        for (int d = 0; d < 3; d++) {
+            const unsigned* h = hist.data() + (d == 0 ? 0 : (d == 1 ? n[0] : n[0] + n[1]));
+            for (idx_t i = 1; i < n[d]; i++)
+                if (h[i] != h[i - 1]) cuts[d].push_back(i);
+            if (!cuts[d].empty() && cuts[d].size() < 8 && (best < 0 || cuts[d].size() < cuts[best].size())) best = d;
+        }
+        if (best < 0) return false;
+        idx_t from = 0;
+        cuts[best].push_back(n[best]);
+        for (idx_t to : cuts[best]) {
+            Box piece = bb;
+            piece.lo[best] = bb.lo[best] + from;
+            piece.hi[best] = bb.lo[best] + to;
+            todo.push_back(Item{piece, it.depth + 1, false, 0});
+            from = to;
+        }
+    }
+    return covered == total && !out.empty();
+}
+
 // ------------------------------------------------------------------ launches
 void Solution::fill_part_args(int part, idx_t t, const Box& box, PartArgs& a) const {
     const PartMeta& pm = *impl.parts[part].meta;
@@ -722,6 +822,16 @@ int Solution::resident_blocks(const KernelVariant& kv) {
 }
 
 void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t, const Box& box_in, hipStream_t s) {
+    // a sub-domain part with a list of full boxes: one launch per box that meets the request (every kernel family is legal there)
+    if (!in_part_boxes_ && (size_t)part < part_boxes.size() && !part_boxes[part].empty()) {
+        ScopedSet<bool> walking(in_part_boxes_, true);
+        for (const Box& fb : part_boxes[part]) {
+            Box b = box_in;
+            for (int d = 0; d < MAX_DOMAIN_DIMS; d++) { b.lo[d] = std::max(b.lo[d], fb.lo[d]); b.hi[d] = std::min(b.hi[d], fb.hi[d]); }
+            if (!b.empty()) launch_part_variant(part, variant, xchunk, t, b, s);
+        }
+        return;
+    }
     // sub-domain parts run inside the bounding box of their condition only; where the condition does not hold
     // everywhere in that box, only the point kernel (which evaluates it per point) is legal
     Box box = box_in;
@@ -803,6 +913,10 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
         }
         kv.launch(a, grid, s);
     } else {
+        // a box that is (nearly) a plane of constant z -- awp's free-surface parts: 512 x 512 x 1 -- would keep ONE lane of each wave
+        // busy with the lanes along z (0.4-0.6 ms for 262 144 points): there the lanes run along y.  Every lane then touches a cache
+        // line of its own, but 64 of them do.
+        if (a.lane_dim == 2 && ndd == 3 && box.hi[2] - box.lo[2] <= 8 && box.hi[1] - box.lo[1] >= 32) a.lane_dim = 1;
         kv.launch(a, point_grid(box, a.lane_dim), s);
     }
     YKH_HIP(hipGetLastError());

@@ -45,6 +45,11 @@ void launch_cond_bb(const PartArgs& a, dim3 grid, int* dev_out, hipStream_t s) {
     hipLaunchKernelGGL((cond_bb_kernel<P>), grid, dim3(256), 0, s, a, dev_out);
 }
 
+template <class P>
+void launch_cond_profile(const PartArgs& a, dim3 grid, unsigned* dev_hist, hipStream_t s) {
+    hipLaunchKernelGGL((cond_profile_kernel<P>), grid, dim3(256), 0, s, a, dev_hist);
+}
+
 // ABL != 0 variants compute WRONG results on purpose (profiling ablations); their names start with
 // "abl" and neither the default selection nor the auto-tuner ever picks them.
 template <class P, int TZL, int TYL, int RY, int ROT, int ABL = 0>

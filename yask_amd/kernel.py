@@ -464,6 +464,14 @@ class yk_solution:
         kind = self._lib.call("yk_solution_get_part_bounding_box", self._h, int(part), first, last)
         return kind, list(first), list(last)
 
+    def get_part_full_boxes(self, part):
+        """The full boxes of a sub-domain part in this rank (the reference's _bb_list): [(first, last), ...] in rank-local indices,
+        last inclusive; [] where there is no list (unconditional, a condition that fills its bounding box, or per-point predicate)."""
+        cap = 64
+        first, last = (idx_t * (3 * cap))(), (idx_t * (3 * cap))()
+        n = self._lib.call("yk_solution_get_part_full_boxes", self._h, int(part), cap, first, last)
+        return [(list(first[3 * i:3 * i + 3]), list(last[3 * i:3 * i + 3])) for i in range(min(n, cap))]
+
     def get_kernel_variant_names(self, part=0):
         n = self._lib.call("yk_solution_get_num_kernel_variants", self._h, part)
         return [self._lib.call("yk_solution_get_kernel_variant_name", self._h, part, i).decode() for i in range(n)]
