@@ -95,6 +95,15 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
                 if constexpr (clusters_legal<P, 2>()) p.variants.push_back(vecpt_cluster_variant<P, 2, VZ, 64, 4, 1>());
                 if constexpr (P::n_writes >= 24 && clusters_legal<P, 8>()) p.variants.push_back(vecpt_cluster_variant<P, 8, VZ, 64, 4, 1>());
             }
+            // sub-domain parts run box by box (Solution::find_part_boxes), and the boxes of a shell include slabs that are thin in z:
+            // a point-kernel tile of 32 z x 32 y keeps 5 of its 8 z lanes busy on a 20-point slab where the 256 x 4 tile keeps 5 of 64
+            if constexpr (P::has_domain_cond) {
+                p.variants.push_back(vecpt_variant<P, VZ, 8, 32, 1>());
+                if constexpr (P::n_writes >= 12) {
+                    if constexpr (clusters_legal<P, 4>()) p.variants.push_back(vecpt_cluster_variant<P, 4, VZ, 8, 32, 1>());
+                    if constexpr (clusters_legal<P, 2>()) p.variants.push_back(vecpt_cluster_variant<P, 2, VZ, 8, 32, 1>());
+                }
+            }
             if constexpr (starlin_eligible<P>()) {
                 p.variants.push_back(starlin_variant<P, VZ, 32, 16, 1, ROT_MOVE, 1, 2, 4>());
                 p.default_variant = (int)p.variants.size() - 1;
