@@ -96,7 +96,8 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
                     if constexpr (march_clusters_fit<P, 4, 2, 64, 8, 0>()) p.variants.push_back(march_cluster_variant<P, 4, 2, 64, 8, 2, 0>());
                 }
                 if constexpr (clusters_legal<P, 2>()) p.variants.push_back(vecpt_cluster_variant<P, 2, VZ, 64, 4, 1>());
-                if constexpr (P::n_writes >= 24 && clusters_legal<P, 8>()) p.variants.push_back(vecpt_cluster_variant<P, 8, VZ, 64, 4, 1>());
+                // (8-byte lanes: 6 % faster on fsg's stress clusters; K = 8, two x planes per thread, 128 x 8 / 64 x 16 tiles: 1-55 % slower, jobs r5p / r5v)
+                if constexpr (P::n_writes >= 24 && VZ == 4 && clusters_legal<P, 4>()) p.variants.push_back(vecpt_cluster_variant<P, 4, 2, 64, 4, 1>());
             }
             // sub-domain parts run box by box (Solution::find_part_boxes), and the boxes of a shell include slabs that are thin in z:
             // a point-kernel tile of 32 z x 32 y keeps 5 of its 8 z lanes busy on a 20-point slab where the 256 x 4 tile keeps 5 of 64
