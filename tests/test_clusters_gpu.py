@@ -63,3 +63,20 @@ def test_cluster_shapes_equal_the_whole_bundle_on_the_point_kernel(gpu, stencil)
         for vn, a in ref.items():
             err = np.abs(got[vn] - a).max() / max(1e-30, np.abs(a).max())
             assert err <= 2e-6, (stencil, name, vn, err)
+
+
+@pytest.mark.parametrize("stencil,world,nr,g", [("fsg", 2, (1, 2, 1), (24, 40, 48)), ("fsg_abc", 8, (2, 2, 2), (48, 56, 64))])
+def test_clusters_and_box_lists_over_ranks_equal_one_rank(gpu, stencil, world, nr, g, monkeypatch):
+    """A decomposed run launches the cluster kernels on exterior slabs and interior boxes (fsg, two ranks); fsg_abc over 8 ranks: every
+    rank finds the full boxes of the absorbing shell inside ITS domain (a corner rank owns three faces of it) and walks them.  Same
+    shapes on every rank and in the one-rank run: the assembled result is the one-rank result bit for bit."""
+    import test_transport_gpu as T
+    monkeypatch.setenv("YASK_TEST_TRANSPORT", "ipc")
+    monkeypatch.setenv("YASK_TEST_EXTRA_OPTS", "")
+    steps = 2
+    parts = T._run_ranks(world, "run", stencil=stencil, g=g, nr=nr, steps=steps)
+    full = T._assemble(parts, stencil, g)
+    one = T._one_rank(stencil, g, steps)
+    for n in T.FIELDS[stencil]:
+        assert np.isfinite(one[n]).all(), n
+        assert np.array_equal(full[n], one[n]), (n, float(np.abs(full[n] - one[n]).max()))

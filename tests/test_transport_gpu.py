@@ -100,12 +100,17 @@ def test_step_alloc_change_reallocates(gpu):
 
 
 # ------------------------------------------------------------------ several ranks, one GPU, native bootstrap + TCP transport
-FIELDS = {"iso3dfd": ["p"], "ssg": O.SSG_FIELDS, "test_boundary_3d": ["A"], "cube": ["A"],
+_FSG = [f"v_{g}_{c}" for g in ("bl", "br", "tl", "tr") for c in "uvw"] + [f"s_{g}_{c}" for g in ("bl", "br", "tl", "tr") for c in ("xx", "yy", "zz", "yz", "xz", "xy")]
+FIELDS = {"iso3dfd": ["p"], "ssg": O.SSG_FIELDS, "test_boundary_3d": ["A"], "cube": ["A"], "fsg": _FSG, "fsg_abc": _FSG,
           "awp_abc": ["vel_x", "vel_y", "vel_z", "stress_xx", "stress_yy", "stress_zz", "stress_xy", "stress_xz", "stress_yz"]}
 KERNEL = {"iso3dfd": "-hip_variant starlin_v4_z128_y16_r1_m_nt_w2_c4 -no-hip_thin_slab_point_kernel",
           "ssg": "-hip_variant march_v2_z128_y8_w2 -no-hip_thin_slab_point_kernel",      # one kernel everywhere: bit-exact vs 1 rank
           "test_boundary_3d": "-hip_variant naive", "awp_abc": "-hip_variant naive",      # (sub-domain parts: the point kernel)
-          "cube": "-hip_variant box_v4_z128_y16_r1_nt_w2 -no-hip_thin_slab_point_kernel"}   # (tests/test_box_kernel_gpu.py)
+          "cube": "-hip_variant box_v4_z128_y16_r1_nt_w2 -no-hip_thin_slab_point_kernel",   # (tests/test_box_kernel_gpu.py)
+          # (tests/test_clusters_gpu.py: both parts as four clusters of equations on the point kernel; the absorbing parts of
+          #  fsg_abc -- box lists per rank -- have no such shape and keep the point kernel)
+          "fsg": "-hip_variant c4_vecpt_v4_z256_y4_x1 -no-hip_thin_slab_point_kernel",
+          "fsg_abc": "-hip_variant naive"}
 
 
 def _init(soln, stencil):
