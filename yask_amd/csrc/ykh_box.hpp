@@ -139,11 +139,10 @@ struct BoxCfg {
 // ...), so the generated expression is walked once and every read brings RY rows -- reads that differ by one in dy share RY - 1 of
 // their LDS rows, and being loads of one basic block with no store between them hipcc merges them (cube, RY = 2: 90 LDS loads per
 // 8 points instead of 150).  Two separate evaluations cannot share anything: their loads are hoisted wholesale and spill.
-// PIN: honour the generated code's pin() after every temporary (strict program order: smallest live ranges -- parts with
-// hundreds of reads over many groups, e.g. tti, otherwise have all their LDS loads hoisted to the top and spill)
-// SPIN ("soft pin"): the same without the memory clobber -- the temporaries keep their program order, loads may still be merged and
-// moved across them
-template <class C, class P, bool PIN = false, bool SPIN = false>
+// (Honouring the generated code's pin() after every temporary -- strict program order, as ykh_march.hpp offers -- was tried for the
+// parts that spill: with a memory clobber, or with a plain register barrier, hipcc repeats the LDS loads per temporary, tti 3.5x as
+// many; what brought tti inside the register file instead is 8-byte lanes, stencil_generic.hip.)
+template <class C, class P>
 struct BoxAcc {
     typedef typename C::T T;
     static constexpr int VZ = C::VZ, RY = C::RY;
@@ -200,15 +199,8 @@ struct BoxAcc {
         }
     }
     template <int G>
-    __device__ __forceinline__ void wr(V v) {
-        out[G] = v;
-        if constexpr (PIN) asm volatile("" : "+v"(out[G]) : : "memory");
-        else if constexpr (SPIN) asm volatile("" : "+v"(out[G]));
-    }
-    __device__ __forceinline__ void pin(V& v) const {
-        if constexpr (PIN) asm volatile("" : "+v"(v) : : "memory");
-        else if constexpr (SPIN) asm volatile("" : "+v"(v));
-    }
+    __device__ __forceinline__ void wr(V v) { out[G] = v; }
+    __device__ __forceinline__ void pin(V&) const {}
     template <int D>
     __device__ __forceinline__ V idx() const {
         return rows([&](auto jc) -> V1 {
@@ -220,7 +212,7 @@ struct BoxAcc {
     __device__ __forceinline__ V step() const { return V(T(a.t)); }
 };
 
-// FL & 1: non-temporal output stores and centre-only operand loads (one-touch streams); FL & 2: PIN, FL & 8: SPIN (BoxAcc);
+// FL & 1: non-temporal output stores and centre-only operand loads (one-touch streams);
 // FL & 4: planes are requested TWO iterations before they are stored into the ring (two register sets; a workgroup's plane takes
 // 1-2.5 us, about a loaded HBM round trip)
 template <class P, int VZ, int TZL, int TYL, int RY, int MINW, int FL = 0, int LDS_KB = 160>
@@ -230,7 +222,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) box_kernel(const PartArgs a) {
     typedef typename vecn<T, VZ>::type V;
     typedef typename vecn<T, VZ * RY>::type VW;
     constexpr int NG = C::NG, NT = C::NT;
-    constexpr bool NTS = (FL & 1) != 0, PIN = (FL & 2) != 0, SPIN = (FL & 8) != 0;
+    constexpr bool NTS = (FL & 1) != 0;
     constexpr int PD = (FL & 4) ? 2 : 1;
     static_assert(NG <= MAX_GROUPS, "too many access groups");
 
@@ -368,7 +360,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) box_kernel(const PartArgs a) {
         static_for<NG>([&](auto gc) { constexpr int g = decltype(gc)::value; if constexpr (C::tab.kind[g] == 1) cur[g] = nxt[g]; });
         if (x + 1 < xe) fetch_once(x + 1);
         {
-            BoxAcc<C, P, PIN, SPIN> acc{a, ring, sl, tofs, cur, x, myy0, myz, out};
+            BoxAcc<C, P> acc{a, ring, sl, tofs, cur, x, myy0, myz, out};
             P::eval(acc);
         }
         static_for<RY>([&](auto jc) {

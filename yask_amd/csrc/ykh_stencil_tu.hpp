@@ -139,13 +139,13 @@ void launch_box(const PartArgs& a, dim3 grid, hipStream_t s) {
     }
     hipLaunchKernelGGL((box_kernel<P, VZ, TZL, TYL, RY, MINW, FL, LDS_KB>), grid, dim3(C::NT), C::lds_bytes, s, a);
 }
-// Plane-ring marching kernel (ykh_box.hpp). Name: box_v<VZ>_z<tile z>_y<tile y>_r<rows per thread>[_nt][_pin][_spin][_p2][_l<LDS budget, KiB>]_w<min waves/SIMD>
+// Plane-ring marching kernel (ykh_box.hpp). Name: box_v<VZ>_z<tile z>_y<tile y>_r<rows per thread>[_nt][_p2][_l<LDS budget, KiB>]_w<min waves/SIMD>
 template <class P, int VZ, int TZL, int TYL, int RY, int MINW, int FL = 0, int LDS_KB = 160>
 KernelVariant box_variant() {
     typedef BoxCfg<P, VZ, TZL, TYL, RY, LDS_KB> C;
     static_assert(C::lds_bytes <= 160 * 1024, "box tile does not fit the 160 KiB LDS");
     static const std::string name = "box_v" + std::to_string(VZ) + "_z" + std::to_string(C::TZ) + "_y" + std::to_string(C::TY) + "_r" +
-                                    std::to_string(RY) + ((FL & 1) ? "_nt" : "") + ((FL & 2) ? "_pin" : "") + ((FL & 8) ? "_spin" : "") + ((FL & 4) ? "_p2" : "") + (LDS_KB != 160 ? "_l" + std::to_string(LDS_KB) : "") +
+                                    std::to_string(RY) + ((FL & 1) ? "_nt" : "") + ((FL & 4) ? "_p2" : "") + (LDS_KB != 160 ? "_l" + std::to_string(LDS_KB) : "") +
                                     "_w" + std::to_string(MINW);
     KernelVariant kv{name.c_str(), true, C::TZ, C::TY, C::lds_bytes, C::NT, &launch_box<P, VZ, TZL, TYL, RY, MINW, FL, LDS_KB>};
     kv.vz = VZ;
