@@ -146,3 +146,28 @@ def test_read_masks_say_which_equations_use_each_read():
             assert len(mine) == len(points), (soln, k, len(mine), len(points))
     # one-equation parts carry no table
     assert "read_wmask" not in (GEN / "iso3dfd_cdna4_hip.hpp").read_text()
+
+
+def test_generic_registry_compiles_for_8_byte_reals(tmp_path):
+    """Any solution may be rendered with 8-byte reals (`-elem-bytes 8`: the reference builds its `real_bytes=8` test matrix that way,
+    src/kernel/Makefile:915-927).  The shipped generic libraries are fp32 (wave2d_f64 is 2-D), so the fp64 instantiations of the
+    3-D kernel families -- the plane-ring kernel with 2-element z-vectors among them -- are compiled nowhere else: cube at 8 bytes
+    through csrc/stencil_generic.hip, device code only, must build, register its plane-ring shapes and spill nothing."""
+    import shutil
+    if not shutil.which("hipcc"):
+        pytest.skip("no hipcc here")
+    csrc = ROOT / "yask_amd" / "csrc"
+    hdr = tmp_path / "cube_f64_cdna4_hip.hpp"
+    r = subprocess.run([str(EXE), "-stencil", "cube", "-target", "cdna4_hip", "-elem-bytes", "8", "-p", str(hdr)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "typedef double real_t;" in hdr.read_text()
+    asm = tmp_path / "cube_f64.s"
+    r = subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", f"-I{csrc}", f"-I{tmp_path}", "-mllvm", "-inline-threshold=1000000",
+                        '-DYKH_GEN_HEADER="cube_f64_cdna4_hip.hpp"', "-DYKH_GEN_NS=ykh_gen_cube", "--cuda-device-only", "-S",
+                        str(csrc / "stencil_generic.hip"), "-o", str(asm)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    txt = asm.read_text()
+    kernels = re.findall(r"\.name:\s+(\S*box_kernel\S*)\n.*?\.private_segment_fixed_size:\s+(\d+)", txt, re.S)
+    assert len(kernels) >= 2, "no plane-ring kernel instantiated for 8-byte reals"
+    assert all("Li2E" in k for k, _ in kernels)                      # 2-element z-vectors (16 bytes of doubles)
+    assert any(int(sc) == 0 for _, sc in kernels), kernels           # at least the one-row shapes keep out of scratch
