@@ -1,0 +1,42 @@
+// Host-side probe of the compile-time tables of the generic kernel families (tests/test_kernel_tables_cpu.py): compiled per solution with
+// -DYKH_GEN_HEADER / -DYKH_GEN_NS like csrc/stencil_generic.hip, host pass only; prints one JSON object per part.
+#include YKH_GEN_HEADER
+#include "ykh_stencil_tu.hpp"
+#include <cstdio>
+using namespace ykh;
+using namespace YKH_GEN_NS;
+
+template <class P, int K>
+void clusters(const char* sep) {
+    if constexpr (P::n_writes > 1) {
+        printf("%s\"k%d\": {\"legal\": %d", sep, K, (int)clusters_legal<P, K>());
+        if constexpr (P::n_writes >= K) {
+            typedef SubPart<P, cluster_mask<P, K>(0)> S0;
+            printf(", \"c0_reads\": %d, \"c0_writes\": %d, \"c0_march_ok\": %d, \"c0_lds_v2_128x8\": %zu", S0::n_reads, S0::n_writes, (int)march_eligible<S0>(),
+                   MarchCfg<S0, 2, 64, 8>::lds_bytes);
+        }
+        printf("}");
+    }
+}
+template <class P>
+void part(const char* name, bool first) {
+    constexpr int VZ = 16 / (int)sizeof(typename P::real_t);
+    typedef BoxCfg<P, VZ, 32, 16, 1> B16;
+    typedef BoxCfg<P, VZ, 32, 8, 1, 80> B8h;
+    typedef BoxCfg<P, VZ, 32, 8, 1> B8;
+    printf("%s{\"part\": \"%s\", \"groups\": %d, \"reads\": %d, \"writes\": %d, \"mixed\": %d, \"box_eligible\": %d, \"march_eligible\": %d,\n"
+           "  \"box_128x16\": {\"lds\": %zu, \"ring_reads\": %d, \"xover\": %d}, \"box_128x8_80k\": {\"lds\": %zu, \"ring_reads\": %d}, \"box_128x8\": {\"lds\": %zu, \"ring_reads\": %d}",
+           first ? "" : ",\n", name, P::n_groups, P::n_reads, P::n_writes, count_mixed<P>(), (int)box_eligible<P>(), (int)march_eligible<P>(),
+           B16::lds_bytes, B16::ring_reads(), B16::XOVER, B8h::lds_bytes, B8h::ring_reads(), B8::lds_bytes, B8::ring_reads());
+    clusters<P, 2>(", ");
+    clusters<P, 4>(", ");
+    printf("}");
+}
+int main() {
+    printf("[");
+    bool first = true;
+#define YKH_PROBE(PART) part<PART>(#PART, first); first = false;
+    YKH_FOR_EACH_PART(YKH_PROBE)
+    printf("]\n");
+    return 0;
+}

@@ -1,0 +1,62 @@
+"""Compile-time tables of the generic kernel families, evaluated on the host (no GPU): tests/cpp/kernel_tables.hip is compiled per
+solution exactly like csrc/stencil_generic.hip (host pass only, ~1.5 s each) and prints what the registry decides from.
+
+* the plane-ring kernel (csrc/ykh_box.hpp `BoxCfg`): ring sizes, the LDS budget (groups take rings in the order of their read counts,
+  what does not fit is read from global memory where used), which parts qualify (more than MAX_MIXED mixed-offset reads);
+* parts as clusters of equations (csrc/ykh_subpart.hpp): the reads of a cluster from the compiler target's `read_wmask`, and the
+  legality rule -- no cluster reads an array another cluster of the part writes, whatever the step offset (step slots alias)."""
+import json
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+CSRC = ROOT / "yask_amd" / "csrc"
+pytestmark = pytest.mark.skipif(not shutil.which("hipcc"), reason="no hipcc here")
+
+
+def tables(tmp_path, soln):
+    exe = tmp_path / f"kt_{soln}"
+    r = subprocess.run(["hipcc", "-O1", "-std=c++17", "--cuda-host-only", f"-I{CSRC}", f'-DYKH_GEN_HEADER="gen/{soln}_cdna4_hip.hpp"',
+                        f"-DYKH_GEN_NS=ykh_gen_{soln}", "-o", str(exe), str(ROOT / "tests" / "cpp" / "kernel_tables.hip")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    return {p["part"]: p for p in json.loads(out)}
+
+
+def test_plane_ring_tables(tmp_path):
+    cube = tables(tmp_path, "cube")["part_1"]
+    assert (cube["reads"], cube["mixed"], cube["box_eligible"]) == (125, 112, 1)
+    # 5 x 5 x 5 around the point: planes x-2 .. x+2 + one free slot, 16 + 4 rows of 128 + 2 x 4 floats
+    assert cube["box_128x16"] == {"lds": 6 * 20 * 136 * 4, "ring_reads": 125, "xover": 5}
+    assert cube["box_128x8_80k"]["lds"] == 6 * 12 * 136 * 4
+    tti = tables(tmp_path, "tti")["part_1"]
+    assert (tti["reads"], tti["mixed"]) == (140, 68)
+    # u(t) and v(t), 47 reads each, take the rings; the four 10-read coefficient arrays fit only two at a time in the whole LDS
+    assert tti["box_128x16"] == {"lds": 2 * 6 * 20 * 136 * 4, "ring_reads": 94, "xover": 5}
+    assert tti["box_128x8_80k"] == {"lds": 2 * 6 * 12 * 136 * 4, "ring_reads": 94}
+    assert tti["box_128x8"]["ring_reads"] == 114 and tti["box_128x8"]["lds"] <= 160 * 1024
+    # a star stencil has no mixed reads: the registry never gives it a plane-ring shape (count_mixed <= MAX_MIXED = 8)
+    iso = tables(tmp_path, "iso3dfd")["part_1"]
+    assert iso["mixed"] == 0 and iso["march_eligible"] == 1
+    t3 = tables(tmp_path, "test_3d")["part_1"]
+    assert t3["mixed"] <= 8
+
+
+def test_equation_clusters_tables(tmp_path):
+    fsg = tables(tmp_path, "fsg")
+    v, s = fsg["part_1"], fsg["part_2"]
+    assert (v["writes"], v["reads"], s["writes"], s["reads"]) == (12, 296, 24, 435)
+    # four clusters = the four sub-grids: 3 velocity / 6 stress components each
+    assert v["k4"]["legal"] == 1 and v["k4"]["c0_writes"] == 3 and v["k4"]["c0_march_ok"] == 1 and v["k4"]["c0_lds_v2_128x8"] <= 160 * 1024
+    assert s["k4"]["legal"] == 1 and (s["k4"]["c0_reads"], s["k4"]["c0_writes"]) == (162, 6)
+    assert s["k4"]["c0_lds_v2_128x8"] > 160 * 1024          # every stress equation needs all nine velocity derivatives: no marching kernel
+    assert s["k2"]["legal"] == 1 and s["k2"]["c0_writes"] == 12
+    # fsg2 keeps its components in two vars with a misc dim: storage identity is (var, misc indices), not the var alone
+    fsg2 = tables(tmp_path, "fsg2")
+    assert fsg2["part_2"]["k4"]["legal"] == 1 and fsg2["part_1"]["k4"]["legal"] == 1
+    # tti's two equations read each other's var (u and v, at other step offsets: the step slots alias): not separable
+    tti = tables(tmp_path, "tti")["part_1"]
+    assert tti["k2"]["legal"] == 0
