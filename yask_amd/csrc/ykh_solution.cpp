@@ -21,6 +21,7 @@
 #include <cstring>
 #include <sstream>
 
+#include "ykh_boxes.hpp"
 #include "ykh_runtime.hpp"
 #include "ykh_solution_internal.hpp"
 
@@ -662,23 +663,22 @@ void Solution::end() {
 }
 
 // ------------------------------------------------------------------ full boxes of a sub-domain condition
-// The reference turns a sub-domain condition into a list of FULL bounding boxes -- non-overlapping rectangles holding valid points
-// only -- by scanning every point on the host (StencilPartBase::find_bounding_boxes, src/kernel/lib/setup.cpp:1235-1500: slices per
-// thread, rectangles grown point by point, merged afterwards).  Here the condition is device code and the grid may hold 2^30
-// points: two reductions do the work.  cond_bb_kernel gives the bounding box and the number of valid points of a query box
-// (count == volume: the box is full); cond_profile_kernel gives the number of valid points per index along x, y and z.  A profile
-// is constant between the planes that bound the region, so a box that is not full is cut at the breakpoints of the dim with the
-// fewest of them and the pieces are examined again.  Regions made of a few slabs (a shell of fixed width: 6 boxes) resolve in
-// three levels; anything that does not -- a slanted or scattered condition -- is left to the point kernel's per-point predicate
-// (returns false; limits: 8 pieces per cut, 64 boxes, 8 levels).  Exact by construction and checked: every emitted box is full
-// and the volumes add up to the number of valid points.
+// The reference's list of FULL bounding boxes of a condition (StencilPartBase::find_bounding_boxes, setup.cpp:1235-1500), found from
+// two device reductions instead of a scan of the points: the algorithm is decompose_full_boxes() (ykh_boxes.hpp, host logic, tested
+// on the CPU); here its two questions are put to the GPU -- cond_bb_kernel (bounding box + number of valid points of a query box)
+// and cond_profile_kernel (valid points per index along x, y, z).
 bool Solution::find_part_boxes(int part, const Box& bb0, unsigned long long total, std::vector<Box>& out) {
     const PartImpl& pi = impl.parts[part];
+    {
+        PartArgs a;
+        fill_part_args(part, 0, bb0, a);
+        if (a.lane_dim != 2) return false;        // (the profile kernel's histogram layout: 3-D solutions, lanes along z)
+    }
     int* dbb = nullptr;
     unsigned* dhist = nullptr;
     YKH_HIP(hipMalloc(&dbb, 8 * sizeof(int)));
     struct Free { int* a; unsigned*& b; ~Free() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } guard{dbb, dhist};
-    auto volume = [&](const Box& b) { unsigned long long v = 1; for (int d = 0; d < 3; d++) v *= (unsigned long long)std::max<idx_t>(0, b.hi[d] - b.lo[d]); return v; };
+    size_t hist_cap = 0;
     auto query = [&](const Box& q, Box& bb) -> unsigned long long {
         const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
         YKH_HIP(hipMemcpyAsync(dbb, init, sizeof(init), hipMemcpyHostToDevice, compute_stream));
@@ -695,29 +695,10 @@ bool Solution::find_part_boxes(int part, const Box& bb0, unsigned long long tota
         if (c) for (int d = 0; d < 3; d++) { bb.lo[d] = o[d]; bb.hi[d] = o[3 + d] + 1; }
         return c;
     };
-    size_t hist_cap = 0;
-    std::vector<unsigned> hist;
-    struct Item { Box b; int depth; bool known; unsigned long long count; };
-    std::vector<Item> todo{{bb0, 0, true, total}};
-    unsigned long long covered = 0;
-    while (!todo.empty()) {
-        Item it = todo.back();
-        todo.pop_back();
-        Box bb = it.b;
-        const unsigned long long c = it.known ? it.count : query(it.b, bb);
-        if (c == 0) continue;
-        if (c == volume(bb)) {
-            out.push_back(bb);
-            covered += c;
-            if (out.size() > 64) return false;
-            continue;
-        }
-        if (it.depth >= 8) return false;
+    auto profile = [&](const Box& bb, std::vector<unsigned>& hist) {
         PartArgs a;
         fill_part_args(part, 0, bb, a);
-        if (a.lane_dim != 2) return false;
-        const idx_t n[3] = {bb.hi[0] - bb.lo[0], bb.hi[1] - bb.lo[1], bb.hi[2] - bb.lo[2]};
-        const size_t need = (size_t)(n[0] + n[1] + n[2]) + 64 + 4;      // (blocks cover 64 z / 4 y: counts of the overhang are zero)
+        const size_t need = hist.size() + 64 + 4;      // (blocks cover 64 z / 4 y: the counts of the overhang are zero)
         if (need > hist_cap) {
             if (dhist) (void)hipFree(dhist);
             dhist = nullptr;
@@ -727,30 +708,10 @@ bool Solution::find_part_boxes(int part, const Box& bb0, unsigned long long tota
         YKH_HIP(hipMemsetAsync(dhist, 0, need * sizeof(unsigned), compute_stream));
         pi.cond_profile(a, point_grid(bb, a.lane_dim), dhist, compute_stream);
         YKH_HIP(hipGetLastError());
-        hist.resize(need);
-        YKH_HIP(hipMemcpyAsync(hist.data(), dhist, need * sizeof(unsigned), hipMemcpyDeviceToHost, compute_stream));
+        YKH_HIP(hipMemcpyAsync(hist.data(), dhist, hist.size() * sizeof(unsigned), hipMemcpyDeviceToHost, compute_stream));
         YKH_HIP(hipStreamSynchronize(compute_stream));
-        // breakpoints per dim; cut along the dim with the fewest pieces (> 1)
-        int best = -1;
-        std::vector<idx_t> cuts[3];
-        for (int d = 0; d < 3; d++) {
-            const unsigned* h = hist.data() + (d == 0 ? 0 : (d == 1 ? n[0] : n[0] + n[1]));
-            for (idx_t i = 1; i < n[d]; i++)
-                if (h[i] != h[i - 1]) cuts[d].push_back(i);
-            if (!cuts[d].empty() && cuts[d].size() < 8 && (best < 0 || cuts[d].size() < cuts[best].size())) best = d;
-        }
-        if (best < 0) return false;
-        idx_t from = 0;
-        cuts[best].push_back(n[best]);
-        for (idx_t to : cuts[best]) {
-            Box piece = bb;
-            piece.lo[best] = bb.lo[best] + from;
-            piece.hi[best] = bb.lo[best] + to;
-            todo.push_back(Item{piece, it.depth + 1, false, 0});
-            from = to;
-        }
-    }
-    return covered == total && !out.empty();
+    };
+    return decompose_full_boxes<Box>(bb0, total, query, profile, out);
 }
 
 // ------------------------------------------------------------------ launches
