@@ -83,7 +83,7 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
                     p.variants.push_back(box_variant<P, VZ, TZL, 8, 1, 2, 1 | 4>());
                     if constexpr (P::n_reads > 130) p.variants.push_back(box_variant<P, VZ, TZL, 8, 1, 1, 1 | 4>());
                     // ... and with 8-byte lanes (two points per thread) such a part fits 256 VGPRs without spilling: 512 threads, two waves
-                    // per SIMD where the 16-byte-lane shape above runs one (tti: 251 VGPRs)
+                    // per SIMD where the 16-byte-lane shape above runs one (tti: 251 VGPRs, no scratch; 256 + 68 B without packed fp32)
                     if constexpr (P::n_reads > 130 && VZ == 4) p.variants.push_back(box_variant<P, 2, 64, 8, 1, 2, 1 | 4>());
                 }
             }
