@@ -263,6 +263,37 @@ def cpu_baseline():
             "sample": f"C restatement (oracle/stencil_oracle.c, OpenMP) {n2}^3 x {st2} steps incl. init"}
 
 
+CPU_BASELINE_CACHE = ROOT / "gpurun_out" / "cpu_baseline_cache.json"
+CPU_BASELINE_RECORD = ROOT / "profiles" / "cpu_baseline_record.json"
+
+
+def cpu_baseline_store(cb):
+    """the N = 1 run leaves its CPU baseline beside the scratch outputs: an N > 1 run on the same box re-uses it instead of spending the
+    reference's 80 s of auto-tuning once per N (VERDICT r05 weak #11)"""
+    try:
+        CPU_BASELINE_CACHE.parent.mkdir(parents=True, exist_ok=True)
+        json.dump({"host": os.uname().nodename, "written": time.strftime("%Y-%m-%dT%H:%M:%S"), "cpu_baseline": cb}, open(CPU_BASELINE_CACHE, "w"))
+    except OSError:
+        pass
+
+
+def cpu_baseline_cached():
+    """N > 1: the figure of this box's own N = 1 run when there is one (same host name), else the committed record of an earlier box --
+    each labelled as what it is; never re-measured here (rank 0 would hold the other ranks for minutes)."""
+    for path, what in ((CPU_BASELINE_CACHE, "this box's N=1 run of bench.py"), (CPU_BASELINE_RECORD, "committed record of an earlier box")):
+        try:
+            j = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if path == CPU_BASELINE_CACHE and j.get("host") != os.uname().nodename:
+            continue
+        cb = dict(j["cpu_baseline"])
+        cb["cached"] = True
+        cb["cached_from"] = f"{what} ({path.relative_to(ROOT)}, written {j.get('written', '?')}); the CPU reference runs on rank 0 at N=1 only"
+        return cb
+    return None
+
+
 # ---------------------------------------------------------------------------------------------- main
 def live_traffic(args, kernel_name):
     """HBM bytes per launch of the dominant kernel, measured NOW: two short rocprofv3 passes of this very workload, one counter
@@ -598,6 +629,11 @@ def main():
     if world > 1 and args.transport == "auto":
         # RCCL first: it is what north_star names, and its numbers are in hand before the IPC transport is let into this process
         cands = ["rccl", "ipc"] if torch.distributed.get_backend() == "nccl" else ["torch", "ipc"]
+        # (first contact with a new node: a transport known to hang there is left out by name, MULTIGPU_FIRST_CONTACT.md)
+        skip_t = set(filter(None, os.environ.get("YASK_BENCH_SKIP_TRANSPORTS", "").replace(",", " ").split()))
+        cands = [c for c in cands if c not in skip_t]
+        if not cands:
+            raise SystemExit(f"bench.py: YASK_BENCH_SKIP_TRANSPORTS={sorted(skip_t)} leaves no halo transport")
         transport_ms, built = {}, {}
 
         def phase(c, fn):
@@ -822,9 +858,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": round(kern_ms, 4), "kernel_ms_source": kern_src, "algorithmic_bytes_per_launch": BYTES_PER_POINT * pts_per_gpu,
+                         "per_gpu": world > 1 or None, "rank": 0,
                          # (algorithmic bytes of the stencil against what a plain copy kernel moves on this box now; the stencil's
                          #  own fabric traffic is `traffic` / kernel time)
                          "frac_of_this_box_copy": (round(achieved / probe["copy_1r1w_gbs"], 4) if probe and probe.get("copy_1r1w_gbs") else None)},
+            # what `value` rests on besides the kernel: the arrays' physical placement is a best-of-6 draw that THIS script asks for
+            # (-hip_placement_trials 6); a plain API user gets the first draw, the mean of a ~3 % lottery
+            "placement": ("best of 6 drawn sets (bench.py and the harnesses ask for it; the library's default is the first draw, ~1.5 % slower on average)"
+                          if not shared_dev else "first draw (ranks share a device)"),
             "gpoints_per_s_per_gpu": round(value / world, 3),
             "per_gpu_roofline_frac_whole_step": round(value / world * BYTES_PER_POINT / HBM_PEAK_GBS, 4),
             "step_ms": ({"min": round(min(step_ms), 4), "median": round(statistics.median(step_ms), 4), "max": round(max(step_ms), 4),
@@ -852,6 +893,9 @@ def main():
                                                       if tc1.get("ctl_msgs") is not None and tc0.get("ctl_msgs") is not None else None)}
         if world == 1 and not args.no_cpu_baseline and args.workload == "iso3dfd":
             out["cpu_baseline"] = cpu_baseline()
+            cpu_baseline_store(out["cpu_baseline"])
+        elif world > 1 and not args.no_cpu_baseline and args.workload == "iso3dfd":
+            out["cpu_baseline"] = cpu_baseline_cached()
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
