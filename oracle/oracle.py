@@ -179,15 +179,20 @@ def load_ref_dump(prefix):
     return out
 
 
-def lattice(n, stride=32, edge=9):
+def lattice(n, stride=32, edge=9, tile=0):
     """Sample indices along one dim for the BASELINE-size fixtures: every point of the `edge`-wide boundary layers
-    (where clamped loads, masks and halo reads live) plus every `stride`-th point in between."""
-    n, stride, edge = int(n), int(stride), int(edge)
+    (where clamped loads, masks and halo reads live) plus every `stride`-th point in between.  tile > 0 (the multi-tile
+    fixtures of the generic kernels): also both sides of every multiple of `tile` -- m-1 and m -- which is where a
+    workgroup's tile ends and its neighbour's begins (tile halos, ring wrap, x-chunk seams)."""
+    n, stride, edge, tile = int(n), int(stride), int(edge), int(tile)
     idx = set(range(min(edge, n))) | set(range(0, n, stride)) | set(range(max(0, n - edge), n))
+    if tile > 0:
+        for m in range(tile, n, tile):
+            idx |= {m - 1, m}
     return np.array(sorted(idx), dtype=np.int64)
 
 
-def lattice_sample(a, stride=32, edge=9):
-    """a[ix][:, iy][:, :, iz] on the lattice of each dim (works on memmaps)."""
-    ix, iy, iz = (lattice(s, stride, edge) for s in a.shape)
+def lattice_sample(a, stride=32, edge=9, tile=0):
+    """a[ix][:, iy][:, :, iz] on the lattice of each of the first three dims (works on memmaps); further dims are kept whole."""
+    ix, iy, iz = (lattice(s, stride, edge, tile) for s in a.shape[:3])
     return np.ascontiguousarray(np.asarray(a[ix])[:, iy][:, :, iz])

@@ -125,6 +125,40 @@ BIG_CASES = [
 ]
 
 
+# Multi-tile fixtures of the generic kernel families.  The GENERIC_CASES above are one-tile grids; what makes
+# the plane-ring box kernel, the equation clusters, the box-list dispatch and the marching kernels non-trivial -- ring wrap across
+# x-chunks, tile halos from neighbouring tiles, prefetch past the chunk, shell boxes thin in z -- only exists on grids of several
+# tiles, and there the only checker used to be another HIP kernel.  Every 3-D generic solution on a ragged 136 x 72 x 264 grid
+# (x: a 128-plane chunk + 8; y: 2 x 32 + 8; z: 2 x 128 + 8 or 4 x 64 + 8), sampled on the lattice of oracle.lattice(stride 16,
+# edge 9, tile 32): all points of the 9-wide boundary layers, every 16th point, and both sides of every multiple of 32 per dim.
+# Only the vars the solution writes (step-indexed) at the last step are kept.
+TILE_SIZE = (136, 72, 264)
+TILE_LATTICE = dict(stride=16, edge=9, tile=32)
+TILE_CASES = [
+    # name suffix _mt = "multi-tile"; (stencil, steps)
+    ("cube", 2), ("3plane", 2), ("3axis_with_diags", 2), ("tti", 2), ("fsg", 2), ("fsg_abc", 2), ("fsg2_abc", 2),
+    ("awp", 2), ("awp_abc", 2), ("awp_elastic_abc", 2), ("iso3dfd_sponge", 3), ("ssg2", 2),
+    ("test_3d", 3), ("test_boundary_3d", 3), ("test_scratch_3d", 2), ("test_stages_3d", 3), ("test_partial_3d", 2), ("test_stream_3d", 3),
+]
+
+
+# Compile-time variants: the cases of the reference's own test matrix that set radius= / domain_dims=
+# (src/kernel/Makefile:1116-1153), built like the reference builds them -- one more library <stencil><suffix> from the same DSL
+# definition with other compiler flags (yask_amd/csrc/variants.mk).  The reference kernel of each variant is built with the SAME flags
+# (oracle/Makefile YC_EXTRA).  Sizes are given in the variant's own domain-dim order (-domain-dims z,x,y: first size = z).
+VARIANT_CASES = [
+    # fixture name, library tag, solution, compiler flags, size, steps[, "reverse"]
+    ("iso3dfd-r3zxy_24x40x136_s3", "iso3dfd-r3zxy", "iso3dfd", "-radius 3 -domain-dims z,x,y", (24, 40, 136), 3),
+    ("iso3dfd_sponge-r6_24x40x136_s3", "iso3dfd_sponge-r6", "iso3dfd_sponge", "-radius 6", (24, 40, 136), 3),
+    ("test_stream_3d-r5_24x40x72_s3", "test_stream_3d-r5", "test_stream_3d", "-radius 5", (24, 40, 72), 3),
+    ("test_3d-zyx_24x40x72_s3", "test_3d-zyx", "test_3d", "-domain-dims z,y,x", (24, 40, 72), 3),
+    ("test_stages_3d-xzy_24x40x72_s3", "test_stages_3d-xzy", "test_stages_3d", "-domain-dims x,z,y", (24, 40, 72), 3),
+    ("test_partial_3d-xzy_24x40x72_s2", "test_partial_3d-xzy", "test_partial_3d", "-domain-dims x,z,y", (24, 40, 72), 2),
+    ("test_2d-yx_72x136_s2", "test_2d-yx", "test_2d", "-domain-dims y,x", (72, 136), 2),
+    ("test_reverse_2d-r1_40x36_s3", "test_reverse_2d-r1", "test_reverse_2d", "-radius 1", (40, 36), 3, "reverse"),
+]
+
+
 def generic_var_names(stencil):
     import re
     txt = (ROOT / "yask_amd" / "csrc" / "gen" / f"{stencil}_cdna4_hip.hpp").read_text()
@@ -133,13 +167,13 @@ def generic_var_names(stencil):
             if m.group(2) == "false"]
 
 
-def ensure_ref(tag, stencil, arch, real_bytes=4):
+def ensure_ref(tag, stencil, arch, real_bytes=4, yc_extra=""):
     """Build the reference kernel + driver of a stencil with oracle/Makefile when it is not there yet (minutes)."""
     exe = REF / f"ref_driver.{tag}.{arch}.exe"
     if not exe.exists():
-        print(f"building the reference kernel of '{stencil}' (oracle/Makefile ref-kernel) ...", flush=True)
-        subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "ref-kernel", f"STENCIL={stencil}", f"TAG={tag}",
-                               f"REAL_BYTES={real_bytes}", f"ARCH={arch}"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        print(f"building the reference kernel of '{stencil}' {yc_extra} (oracle/Makefile ref-kernel) ...", flush=True)
+        subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "-j8", "ref-kernel", f"STENCIL={stencil}", f"TAG={tag}",
+                               f"REAL_BYTES={real_bytes}", f"ARCH={arch}", f"YC_EXTRA={yc_extra}"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return exe
 
 
@@ -221,6 +255,46 @@ def main():
                        "init": O.DEFAULT_INIT[key], "lattice_stride": stride, "lattice_edge": 9}
         if "_r1_" in tag:
             index[name]["radius"] = 1
+        print("wrote", name, {k: v.shape for k, v in arrays.items()})
+    for name, tag, stencil, flags, size, steps, *rest in VARIANT_CASES:
+        if only and name not in only:
+            continue
+        reverse = bool(rest) and rest[0] == "reverse"
+        exe = ensure_ref(tag, stencil, arch, yc_extra=flags)
+        with tempfile.TemporaryDirectory() as td:
+            cmd = [str(exe), "-g", *map(str, size), "-steps", str(steps), "-out", f"{td}/o"] + (["-reverse"] if reverse else [])
+            for v in generic_var_names(tag):
+                cmd += ["-init", f"{v}:{GENERIC_INIT[0]}:{GENERIC_INIT[1]}"]
+            subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dump = O.load_ref_dump(f"{td}/o")
+        arrays = {f"{n}@{t}": a for (n, t), a in dump.items()}
+        np.savez_compressed(HERE / f"{name}.npz", **arrays)
+        index[name] = {"stencil": tag, "solution": stencil, "compiler_flags": flags, "size": list(size), "steps": steps, "arch": arch,
+                       "arrays": sorted(arrays), "variant": True, "init": list(GENERIC_INIT), "reverse": reverse}
+        print("wrote", name, {k: v.shape for k, v in arrays.items()})
+    for stencil, steps in TILE_CASES:
+        name = f"{stencil}_{'x'.join(map(str, TILE_SIZE))}_s{steps}_mt"
+        if only and name not in only:
+            continue
+        exe = ensure_ref(stencil, stencil, arch)
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            cmd = [str(exe), "-g", *map(str, TILE_SIZE), "-steps", str(steps), "-out", f"{td}/o"]
+            for v in generic_var_names(stencil):
+                cmd += ["-init", f"{v}:{GENERIC_INIT[0]}:{GENERIC_INIT[1]}"]
+            subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            man = json.load(open(f"{td}/o.json"))
+            dt = np.float32 if man["elem_bytes"] == 4 else np.float64
+            arrays = {}
+            for v in man["vars"]:
+                if not v["has_step"] or v["step"] != steps or len(v["shape"]) < 3:
+                    continue
+                a = np.memmap(f"{td}/{v['file']}", dtype=dt, mode="r", shape=tuple(v["shape"]))
+                # (x, y, z[, misc ...]): the lattice in the three domain dims, every index of trailing misc dims (ssg2 / fsg2: v(t,x,y,z,vidx))
+                assert tuple(v["shape"][:3]) == TILE_SIZE, (v["name"], v["shape"])
+                arrays[f"{v['name']}@{v['step']}"] = O.lattice_sample(a, **TILE_LATTICE)
+        np.savez_compressed(HERE / f"{name}.npz", **arrays)
+        index[name] = {"stencil": stencil, "size": list(TILE_SIZE), "steps": steps, "arch": arch, "arrays": sorted(arrays),
+                       "multi_tile": True, "init": list(GENERIC_INIT), "lattice": TILE_LATTICE}
         print("wrote", name, {k: v.shape for k, v in arrays.items()})
     if only:       # partial regeneration: keep the other entries
         old = json.load(open(HERE / "index.json"))

@@ -97,7 +97,10 @@ namespace yask {
             vector<Group> groups;            // access groups of the part being emitted
             vector<Off> reads;               // distinct reads
             vector<unsigned long long> read_wmask;   // per read: bit k = equation k of the part (the one that writes writes[k]) uses it
-            int cur_eq = 0;                  // equation being visited
+            int cur_eq = 0;                  // equation being visited = index in writes[] of the group it writes
+            bool dup_writes = false;         // two equations of the part write the same group: read_wmask cannot name equations by writes[] index
+            vector<int> read_log;            // indices into reads[] in the order they were touched (temps remember their slice of it)
+            map<string, vector<int>> temp_reads;     // temp's expr string -> the reads its value depends on
             vector<int> writes;              // groups written
             ostringstream body;              // statements
             map<string, string> memo;        // expr string -> temp name
@@ -114,15 +117,33 @@ namespace yask {
                 groups.push_back(g);
                 return (int)groups.size() - 1;
             }
+            int find_group(const Group& g) const {
+                for (size_t i = 0; i < groups.size(); i++)
+                    if (!(groups[i] < g) && !(g < groups[i])) return (int)i;
+                return -1;
+            }
             void note_read(int g, const int* o) {
                 const unsigned long long bit = cur_eq < 64 ? 1ull << cur_eq : 0ull;
                 for (size_t i = 0; i < reads.size(); i++) {
                     auto& r = reads[i];
-                    if (r.g == g && r.d[0] == o[0] && r.d[1] == o[1] && r.d[2] == o[2]) { read_wmask[i] |= bit; return; }
+                    if (r.g == g && r.d[0] == o[0] && r.d[1] == o[1] && r.d[2] == o[2]) { read_wmask[i] |= bit; read_log.push_back((int)i); return; }
                 }
                 reads.push_back(Off{g, {o[0], o[1], o[2]}});
                 read_wmask.push_back(bit);
+                read_log.push_back((int)reads.size() - 1);
             }
+            // A sub-expression an EARLIER equation already evaluated into a temp: the current equation uses that temp, hence every read
+            // the temp's value depends on (without this a cluster holding only the later equation would see those reads as
+            // "not mine" and evaluate the shared temp from zeros).
+            bool reuse_temp(const string& key, string& name) {
+                auto it = memo.find(key);
+                if (it == memo.end()) return false;
+                const unsigned long long bit = cur_eq < 64 ? 1ull << cur_eq : 0ull;
+                for (int i : temp_reads[key]) { read_wmask[i] |= bit; read_log.push_back(i); }
+                name = it->second;
+                return true;
+            }
+            void close_temp(const string& key, size_t mark) { temp_reads[key] = vector<int>(read_log.begin() + mark, read_log.end()); }
             string temp(const string& key, const string& rhs) {
                 auto it = memo.find(key);
                 if (it != memo.end()) return it->second;
@@ -154,11 +175,26 @@ namespace yask {
             }
             string visit(UnaryNumExpr* ue) override {
                 if (lin_node == ue) return "lin_sum";
+                const string key = ue->make_str();
+                string had;
+                if (reuse_temp(key, had)) return had;
+                const size_t mark = read_log.size();
                 string r = ue->_get_rhs()->accept(this);
-                return temp(ue->make_str(), ue->get_op_str() + "(" + r + ")");
+                string n = temp(key, ue->get_op_str() + "(" + r + ")");
+                close_temp(key, mark);
+                return n;
             }
             string visit(BinaryNumExpr* be) override {
                 if (lin_node == be) return "lin_sum";
+                const string key = be->make_str();
+                string had;
+                if (reuse_temp(key, had)) return had;
+                const size_t mark = read_log.size();
+                string n = visit_binary(be);
+                close_temp(key, mark);
+                return n;
+            }
+            string visit_binary(BinaryNumExpr* be) {
                 string l = be->_get_lhs()->accept(this);
                 string r = be->_get_rhs()->accept(this);
                 if (be->get_op_str() == "%") return fail("modulo operator");
@@ -171,29 +207,48 @@ namespace yask {
             }
             string visit(CommutativeExpr* ce) override {
                 if (lin_node == ce) return "lin_sum";
+                const string key = ce->make_str();
+                string had;
+                if (reuse_temp(key, had)) return had;
+                const size_t mark = read_log.size();
                 string s;
                 for (auto& op : ce->get_ops()) {
                     string o = op->accept(this);
                     s += (s.empty() ? "" : " " + ce->get_op_str() + " ") + o;
                 }
-                return temp(ce->make_str(), s);
+                string n = temp(key, s);
+                close_temp(key, mark);
+                return n;
             }
             string visit(FuncExpr* fe) override {
+                const string key = fe->make_str();
+                string had;
+                if (reuse_temp(key, had)) return had;
+                const size_t mark = read_log.size();
                 string s = "ykh::fn_" + fe->get_op_str() + "(";
                 bool first = true;
                 for (auto& op : fe->get_ops()) { s += string(first ? "" : ", ") + "V(" + op->accept(this) + ")"; first = false; }
-                return temp(fe->make_str(), s + ")");
+                string n = temp(key, s + ")");
+                close_temp(key, mark);
+                return n;
             }
             string visit(UnaryNum2BoolExpr*) override { return fail("boolean expression in a value"); }
             string visit(UnaryBoolExpr*) override { return fail("boolean expression in a value"); }
             string visit(BinaryNum2BoolExpr*) override { return fail("boolean expression in a value"); }
             string visit(BinaryBoolExpr*) override { return fail("boolean expression in a value"); }
             string visit(EqualsExpr* ee) override {
-                cur_eq = (int)writes.size();         // (every equation of a part writes another group: its index in writes[])
-                string rhs = ee->_get_rhs()->accept(this);
                 Group g; int o[3];
                 VarPoint* lhs = ee->_get_lhs().get();
                 if (!point_info(dc, lhs, g, o) || o[0] || o[1] || o[2]) return fail("write that is not at the centre point");
+                // the equation's number = the index its written group has (or is about to get) in writes[]; the group itself is only
+                // registered AFTER the right-hand side, so that the numbering of the groups stays "in order of first use"
+                cur_eq = (int)writes.size();
+                {
+                    const int known = find_group(g);
+                    for (size_t k = 0; known >= 0 && k < writes.size(); k++)
+                        if (writes[k] == known) { cur_eq = (int)k; dup_writes = true; }     // a second equation for the same group
+                }
+                string rhs = ee->_get_rhs()->accept(this);
                 int gi = group_of(g);
                 bool have = false;
                 for (int w : writes) have |= (w == gi);
@@ -553,11 +608,15 @@ namespace yask {
                 os << "};\n";
                 // which equations use each read (bit k = the equation that writes writes[k]): lets the runtime evaluate a part as
                 // several clusters of its equations, each a kernel over the reads it needs (csrc/ykh_subpart.hpp)
-                if (em.writes.size() > 1 && em.writes.size() <= 64) {
-                    os << "    static constexpr unsigned long long read_wmask[" << (em.reads.size() ? em.reads.size() : 1) << "] = {";
-                    for (size_t i = 0; i < em.reads.size(); i++)
+                // (has_read_wmask = false -- more than 64 equations, or two equations writing one group -- switches the clusters off:
+                //  clusters_legal<P, K>() in csrc/ykh_subpart.hpp; the array is then a one-element dummy so that the name exists)
+                const bool wm_ok = em.writes.size() > 1 && em.writes.size() <= 64 && !em.dup_writes;
+                if (em.writes.size() > 1) {
+                    os << "    static constexpr bool has_read_wmask = " << (wm_ok ? "true" : "false") << ";\n";
+                    os << "    static constexpr unsigned long long read_wmask[" << (wm_ok && em.reads.size() ? em.reads.size() : 1) << "] = {";
+                    for (size_t i = 0; wm_ok && i < em.reads.size(); i++)
                         os << (i % 12 == 0 ? "\n        " : " ") << "0x" << hex << em.read_wmask[i] << dec << "ull" << (i + 1 < em.reads.size() ? "," : "");
-                    if (em.reads.empty()) os << "0ull";
+                    if (!wm_ok || em.reads.empty()) os << "0ull";
                     os << "};\n";
                 }
                 os << "    static constexpr int n_writes = " << em.writes.size() << ";\n"

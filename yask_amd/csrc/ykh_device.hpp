@@ -89,6 +89,8 @@ struct PartArgs {
     unsigned* sig;                // [0] running count of finished signalling blocks, [1] published epoch, [2] waiter's error flag
     unsigned sig_goal;            // the block that raises sig[0] to this value publishes ...
     unsigned sig_epoch;           // ... this epoch in sig[1]: the comm stream's wait_epoch_kernel then lets the halo exchange start
+    int xcd_map;                  // experiment knob (YASK_HIP_XCD_MAP, read by kernels of -DYKH_PROFILING builds only): 0 = XCD strips,
+                                  // 1 = 4 (y) x 2 (z) XCD blocks, 2 = 2 (y) x 4 (z)  (profiles/r6_iso3dfd_fetch)
 };
 
 // The (y, z) tile and x range of the calling workgroup of a marching kernel.  Stores are clipped to the launch's box x0..z1
@@ -115,9 +117,22 @@ __device__ __forceinline__ BlockBox block_box(const PartArgs& a) {
     const int ntiles = a.ntz * a.nty * a.nxc;
     int bid = blockIdx.x;
     if ((ntiles & 7) == 0) bid = (bid & 7) * (ntiles >> 3) + (bid >> 3);
-    const int tz_i = bid % a.ntz;
-    const int ty_i = (bid / a.ntz) % a.nty;
+    int tz_i = bid % a.ntz;
+    int ty_i = (bid / a.ntz) % a.nty;
     const int xc_i = bid / (a.ntz * a.nty);
+#ifdef YKH_PROFILING
+    // round-6 experiment: each XCD owns a BLOCK of the (y, z) tile grid instead of a strip of whole tile rows -- fewer rows of
+    // y halo shared between XCDs, but z seams whose 8-float halo costs a whole 128-byte line per row (refuted: profiles/r6_iso3dfd_fetch)
+    if (a.xcd_map > 0 && a.nxc == 1) {
+        const int by = a.xcd_map == 1 ? 4 : 2, bz = 8 / by;          // XCD grid: by along y, bz along z
+        if (a.nty % by == 0 && a.ntz % bz == 0) {
+            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, rz = a.ntz / bz, ry = a.nty / by;
+            tz_i = (xcd % bz) * rz + j % rz;
+            ty_i = (xcd / bz) * ry + j / rz;
+            (void)ry;
+        }
+    }
+#endif
     b.zt0 = (a.z0 & ~(VZ - 1)) + tz_i * TZ;
     b.yt0 = a.y0 + ty_i * TY;
     b.xs = a.x0 + xc_i * a.xchunk;
@@ -156,17 +171,24 @@ __device__ __forceinline__ void block_done(const PartArgs& a, int flags) {
 template <int LS_K>
 __device__ __forceinline__ void xcd_lockstep(unsigned* sig, int d, int step, bool& dead) {
     if constexpr (LS_K > 0) {
-        const int k = d / LS_K;                      // uniform
-        if (sig && !dead && k > 0 && d - k * LS_K < step && threadIdx.x == 0) {
+        // multiples of LS_K reached by now and by the previous trip: a trip longer than LS_K planes (sweep shapes with long trips)
+        // crosses several at once and counts in for each of them, so that the goal -- k arrivals per workgroup -- stays reachable
+        // (with one arrival per trip and step > LS_K every block ran into the poll limit, silently)
+        const int k = d / LS_K, k_prev = d >= step ? (d - step) / LS_K : 0;                     // uniform
+        if (sig && !dead && k > k_prev && threadIdx.x == 0) {
             unsigned* c = sig + (blockIdx.x & 7) * 32;
             const unsigned goal = (unsigned)k * (gridDim.x >> 3);
-            __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(c, (unsigned)(k - k_prev), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int spin = 0;
             for (; spin < 400; spin++) {
                 if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= goal) break;
                 __builtin_amdgcn_s_sleep(2);
             }
-            if (spin == 400) dead = true;
+            if (spin == 400) {
+                dead = true;
+                // c[1]: workgroups of this XCD that gave up (read back and reported under -trace, Solution::launch_part_variant)
+                __hip_atomic_fetch_add(c + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -459,9 +481,22 @@ __global__ void __launch_bounds__(TZL* TYL) star25d_kernel(const PartArgs a) {
     const int ntiles = a.ntz * a.nty * a.nxc;
     int bid = blockIdx.x;
     if ((ntiles & 7) == 0) bid = (bid & 7) * (ntiles >> 3) + (bid >> 3);
-    const int tz_i = bid % a.ntz;
-    const int ty_i = (bid / a.ntz) % a.nty;
+    int tz_i = bid % a.ntz;
+    int ty_i = (bid / a.ntz) % a.nty;
     const int xc_i = bid / (a.ntz * a.nty);
+#ifdef YKH_PROFILING
+    // round-6 experiment: each XCD owns a BLOCK of the (y, z) tile grid instead of a strip of whole tile rows -- fewer rows of
+    // y halo shared between XCDs, but z seams whose 8-float halo costs a whole 128-byte line per row (refuted: profiles/r6_iso3dfd_fetch)
+    if (a.xcd_map > 0 && a.nxc == 1) {
+        const int by = a.xcd_map == 1 ? 4 : 2, bz = 8 / by;          // XCD grid: by along y, bz along z
+        if (a.nty % by == 0 && a.ntz % bz == 0) {
+            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, rz = a.ntz / bz, ry = a.nty / by;
+            tz_i = (xcd % bz) * rz + j % rz;
+            ty_i = (xcd / bz) * ry + j / rz;
+            (void)ry;
+        }
+    }
+#endif
 
     const int tid = threadIdx.x;
     const int lz = tid % TZL, ly = tid / TZL;

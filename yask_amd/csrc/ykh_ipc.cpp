@@ -43,6 +43,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -127,11 +128,17 @@ bool export_buf(IpcState* st, void* p, hipIpcMemHandle_t* h, unsigned long long*
 }
 // hipIpcOpenMemHandle() with a time limit.  The call has been seen to NEVER return (two processes mapping each other's multi-GB
 // allocations at the same instant; tools/microbench/ipc_open.hip is the stand-alone probe): it runs on a helper
-// thread, and a caller that has waited `limit_s` gets hipErrorNotReady -- an exception in the host instead of a hung job.  The helper
-// of a call that timed out is abandoned (the job is failing anyway); a normal open costs one thread start (~50 us, first use of a
-// channel only).
+// thread, and a caller that has waited `limit_s` gets hipErrorNotReady -- an exception in the host instead of a hung job.  A normal
+// open costs one thread start (~50 us, first use of a channel only).
+// After a time-out: the helper is still INSIDE the HIP runtime.  The transport is marked wedged for the life of the process
+// (`ipc_wedged`): ipc_free() then neither synchronises the device nor closes mappings (either may block behind the stuck call, which
+// is the hang the time limit was there to prevent), every later open fails at once, and a helper that does come back late closes the
+// mapping it got instead of leaking it.  A host that sees this error should leave through _exit(): normal teardown would run the HIP
+// runtime's exit handlers with a thread still inside it.
+std::atomic<bool> ipc_wedged{false};
 hipError_t open_guarded(void** base, const hipIpcMemHandle_t& h, double limit_s) {
-    struct Job { std::mutex m; std::condition_variable cv; bool done = false; hipError_t rc = hipErrorUnknown; void* base = nullptr; hipIpcMemHandle_t h; int dev = 0; };
+    struct Job { std::mutex m; std::condition_variable cv; bool done = false, abandoned = false; hipError_t rc = hipErrorUnknown; void* base = nullptr; hipIpcMemHandle_t h; int dev = 0; };
+    if (ipc_wedged.load()) return hipErrorNotReady;
     auto job = std::make_shared<Job>();
     job->h = h;
     (void)hipGetDevice(&job->dev);
@@ -140,16 +147,28 @@ hipError_t open_guarded(void** base, const hipIpcMemHandle_t& h, double limit_s)
         hipError_t rc = hipSetDevice(job->dev);
         if (rc == hipSuccess) rc = hipIpcOpenMemHandle(&b, job->h, hipIpcMemLazyEnablePeerAccess);
         if (rc != hipSuccess) (void)hipGetLastError();
-        std::lock_guard<std::mutex> g(job->m);
-        job->rc = rc; job->base = b; job->done = true;
-        job->cv.notify_all();
+        bool late;
+        {
+            std::lock_guard<std::mutex> g(job->m);
+            job->rc = rc; job->base = b; job->done = true;
+            late = job->abandoned;
+            job->cv.notify_all();
+        }
+        if (late && rc == hipSuccess && b) (void)hipIpcCloseMemHandle(b);      // nobody will ever record this mapping: give it back
     }).detach();
     std::unique_lock<std::mutex> lk(job->m);
-    if (!job->cv.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return job->done; })) return hipErrorNotReady;
+    if (!job->cv.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return job->done; })) {
+        job->abandoned = true;
+        ipc_wedged.store(true);
+        return hipErrorNotReady;
+    }
     *base = job->base;
     return job->rc;
 }
-const char* open_error(hipError_t rc) { return rc == hipErrorNotReady ? "hipIpcOpenMemHandle did not return within the time limit (YASK_HIP_WAIT_TIMEOUT_S)" : hipGetErrorString(rc); }
+const char* open_error(hipError_t rc) {
+    return rc == hipErrorNotReady ? "hipIpcOpenMemHandle did not return within the time limit (YASK_HIP_WAIT_TIMEOUT_S); the IPC transport is disabled for "
+                                    "the rest of this process, which should leave through _exit()" : hipGetErrorString(rc);
+}
 
 void* import_buf(IpcState* st, int peer, const hipIpcMemHandle_t& h) {
     std::string key = std::to_string(peer) + ":" + std::string((const char*)&h, sizeof(h));
@@ -396,6 +415,14 @@ void unmap_mailbox(int kind, unsigned* dev, void* host, size_t bytes, bool mine)
 }
 void ipc_free(void* p) {
     IpcState* st = static_cast<IpcState*>(p);
+    if (ipc_wedged.load()) {
+        // a helper thread is stuck inside hipIpcOpenMemHandle (open_guarded): no call that may queue behind it.  The host-side
+        // resources go; the device-side ones (mappings, the mailbox) stay until the process ends.
+        if (!st->shm_name.empty()) (void)shm_unlink(st->shm_name.c_str());
+        if (st->mesh) { for (int fd : st->mesh->fd) if (fd >= 0) ::close(fd); delete st->mesh; }
+        delete st;
+        return;
+    }
     (void)hipDeviceSynchronize();
     const size_t mb = st->mailbox_words * sizeof(unsigned);
     for (auto& kv : st->opened) (void)hipIpcCloseMemHandle(kv.second);

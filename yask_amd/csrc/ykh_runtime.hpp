@@ -55,8 +55,12 @@ struct KernelVariant {
     const void* func_desc = nullptr;
     int xover = 0;                // plane-iterations of overhead per block (prologue; the planner's cost model)
     bool lockstep = false;        // "_ls<K>" shapes: PartArgs::sig = 8 zeroed per-XCD counters, see starlin_kernel
+    // cluster variants ("c<K>_*": K kernels behind one launch function): the kernels of clusters 1 .. K-1 (func is cluster 0's)
+    const void* more_funcs[7] = {};
+    int n_more_funcs = 0;
 };
-// bytes of scratch (private segment) per thread of a variant's kernel; > 0 means hipcc spilled registers
+// bytes of scratch (private segment) per thread of a variant's kernel(s) -- the maximum over the kernels of a cluster variant;
+// > 0 means hipcc spilled registers
 size_t variant_scratch_bytes(const KernelVariant& kv);
 // Two-steps-per-pass kernel of a part (ykh_starlin2.hpp), when the part has one: not a variant of the one-step
 // kernels (it reads ptr[0] = S(t), the pads of ptr[1] = the t+1 slot, and writes S(t+2) to ptr[2]).
@@ -466,7 +470,7 @@ public:
     struct LaunchPlan { std::string key; BlockPlan plan; BlockDesc* dev = nullptr; size_t cut = 0; };      // cut: end of the round that holds the last shell block
     std::vector<std::unique_ptr<LaunchPlan>> launch_plans;
     unsigned* lockstep_dev = nullptr;  // per-XCD arrival counters of the "_ls<K>" shapes (8 x 32 words), zeroed before each such launch
-    std::map<const void*, int> resident_cache_;
+    std::map<std::tuple<const void*, int, size_t>, int> resident_cache_;
     int resident_blocks(const KernelVariant& kv);
     bool shell_event_pending = false;  // ev_shell was recorded behind the shell part of the launch just issued
     hipEvent_t ev_shell = nullptr;

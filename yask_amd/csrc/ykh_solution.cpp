@@ -62,10 +62,16 @@ long long Env::min_over_ranks(long long v) const { return env_reduce(*this, 1, v
 long long Env::max_over_ranks(long long v) const { return env_reduce(*this, 2, v); }
 
 size_t variant_scratch_bytes(const KernelVariant& kv) {
-    if (!kv.func) return 0;
-    hipFuncAttributes at;
-    if (hipFuncGetAttributes(&at, kv.func) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    return at.localSizeBytes;
+    size_t worst = 0;
+    auto one = [&](const void* f) {
+        hipFuncAttributes at;
+        if (!f) return;
+        if (hipFuncGetAttributes(&at, f) != hipSuccess) { (void)hipGetLastError(); return; }
+        worst = std::max(worst, (size_t)at.localSizeBytes);
+    };
+    one(kv.func);
+    for (int i = 0; i < kv.n_more_funcs; i++) one(kv.more_funcs[i]);      // (a cluster variant is K kernels, not its first)
+    return worst;
 }
 
 // ------------------------------------------------------------------ Solution basics
@@ -770,15 +776,27 @@ void Solution::fill_part_args(int part, idx_t t, const Box& box, PartArgs& a) co
     a.dom_y1 = (int)(ndd > 1 ? local_size[1] : 1);
     a.dom_z1 = (int)(ndd > 2 ? local_size[2] : 1);
     a.lane_dim = std::max(0, std::min(2, ndd - 1));
+    // (experiment knob of -DYKH_PROFILING kernel builds, profiles/r6_iso3dfd_fetch; shipped kernels never read it)
+    static const int xcd_map_env = [] { const char* e = getenv("YASK_HIP_XCD_MAP"); return e ? atoi(e) : 0; }();
+    a.xcd_map = xcd_map_env;
 }
 
 // workgroups of a kernel shape that one CU holds at a time (registers, LDS, waves), asked of the runtime once per shape
 int Solution::resident_blocks(const KernelVariant& kv) {
-    auto it = resident_cache_.find(kv.func);
+    // (keyed by kernel AND launch shape; a failing query is not remembered -- ADVICE r05: the question used to be asked before the
+    //  shape's first launch had raised the kernel's dynamic-LDS limit, answered with an error, and the lock-step shape then ran as
+    //  its plain sibling for the life of the Solution, without a trace)
+    const auto key = std::make_tuple(kv.func, kv.threads, kv.lds_bytes);
+    auto it = resident_cache_.find(key);
     if (it != resident_cache_.end()) return it->second;
     int n = 0;
-    if (!kv.func || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kv.func, kv.threads, kv.lds_bytes) != hipSuccess) { (void)hipGetLastError(); n = 0; }
-    resident_cache_[kv.func] = n;
+    if (kv.func) {
+        if (kv.lds_bytes > 48 * 1024)     // what the shape's launch() does on first use (ykh_stencil_tu.hpp)
+            (void)hipFuncSetAttribute(kv.func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kv.lds_bytes);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kv.func, kv.threads, kv.lds_bytes) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    }
+    if (n > 0) resident_cache_[key] = n;
+    else if (env->trace) fprintf(stderr, "yask-hip: occupancy query of kernel shape '%s' failed: a lock-step shape runs as its plain sibling\n", kv.name);
     return n;
 }
 
@@ -866,13 +884,26 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
         // "_ls<K>" shapes: the workgroups of an XCD keep within K planes of each other (starlin_kernel, xcd_sync).  Only where the
         // hand-shake can complete: block i on XCD i % 8 with equal shares (grid a multiple of 8), every block of the launch resident at
         // once, and every block with the same number of planes to march (equal x-chunks) -- else the shape runs as its plain sibling.
-        if (kv.lockstep && (grid.x & 7) == 0 && nx % a.nxc == 0 && (idx_t)a.xchunk * a.nxc == nx &&
-            (idx_t)grid.x <= (idx_t)resident_blocks(kv) * std::max(1, env->num_cus)) {
-            if (!lockstep_dev) YKH_HIP(hipMalloc(&lockstep_dev, 8 * 32 * sizeof(unsigned)));
-            YKH_HIP(hipMemsetAsync(lockstep_dev, 0, 8 * 32 * sizeof(unsigned), s));
-            a.sig = lockstep_dev;
+        if (kv.lockstep) {
+            if ((grid.x & 7) == 0 && nx % a.nxc == 0 && (idx_t)a.xchunk * a.nxc == nx &&
+                (idx_t)grid.x <= (idx_t)resident_blocks(kv) * std::max(1, env->num_cus)) {
+                if (!lockstep_dev) YKH_HIP(hipMalloc(&lockstep_dev, 8 * 32 * sizeof(unsigned)));
+                YKH_HIP(hipMemsetAsync(lockstep_dev, 0, 8 * 32 * sizeof(unsigned), s));
+                a.sig = lockstep_dev;
+            } else if (env->trace)
+                fprintf(stderr, "yask-hip: lock-step shape '%s' runs without its hand-shake on this launch (grid %u, %lld x-chunks of %d over %lld planes)\n",
+                        kv.name, grid.x, (long long)a.nxc, a.xchunk, (long long)nx);
         }
         kv.launch(a, grid, s);
+        if (a.sig && kv.lockstep && env->trace) {
+            // -trace: did any workgroup give up waiting for its XCD (400 polls)?  Such a launch is slower AND its A/B numbers are polluted
+            unsigned h[8 * 32];
+            YKH_HIP(hipMemcpyAsync(h, lockstep_dev, sizeof(h), hipMemcpyDeviceToHost, s));
+            YKH_HIP(hipStreamSynchronize(s));
+            unsigned gave_up = 0;
+            for (int i = 0; i < 8; i++) gave_up += h[i * 32 + 1];
+            if (gave_up) fprintf(stderr, "yask-hip: lock-step of '%s': %u of %u workgroups timed out waiting for their XCD\n", kv.name, gave_up, grid.x);
+        }
     } else {
         // a box that is (nearly) a plane of constant z -- awp's free-surface parts: 512 x 512 x 1 -- would keep ONE lane of each wave
         // busy with the lanes along z (0.4-0.6 ms for 262 144 points): there the lanes run along y.  Every lane then touches a cache

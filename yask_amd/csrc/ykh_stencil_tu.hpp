@@ -172,6 +172,11 @@ KernelVariant vecpt_cluster_variant() {
     static const std::string name = "c" + std::to_string(K) + "_" + kv.name;
     kv.name = name.c_str();
     kv.launch = &launch_vecpt_clusters<P, K, VZ, TZL, TYL, RX>;
+    static_assert(K - 1 <= 7, "KernelVariant::more_funcs");
+    static_for<K - 1>([&](auto cc) {
+        constexpr int c = decltype(cc)::value + 1;
+        kv.more_funcs[kv.n_more_funcs++] = vecpt_variant<SubPart<P, cluster_mask<P, K>(c)>, VZ, TZL, TYL, RX>().func;
+    });
     return kv;
 }
 template <class P, int K, int VZ, int TZL, int TYL, int MINW, int NT, int... C>
@@ -204,6 +209,11 @@ KernelVariant march_cluster_variant() {
     kv.name = name.c_str();
     kv.launch = &launch_march_clusters<P, K, VZ, TZL, TYL, MINW, NT>;
     kv.lds_bytes = march_clusters_lds_<P, K, VZ, TZL, TYL, NT>(std::make_integer_sequence<int, K>{});
+    static_assert(K - 1 <= 7, "KernelVariant::more_funcs");
+    static_for<K - 1>([&](auto cc) {
+        constexpr int c = decltype(cc)::value + 1;
+        kv.more_funcs[kv.n_more_funcs++] = march_variant<SubPart<P, cluster_mask<P, K>(c)>, VZ, TZL, TYL, MINW, 1, false, 1, NT>().func;
+    });
     return kv;
 }
 

@@ -115,6 +115,7 @@ constexpr bool same_storage(const AccessGroup& a, const AccessGroup& b) {
 template <class P, int K>
 constexpr bool clusters_legal() {
     if (P::n_writes < K || P::n_writes > 64) return false;
+    if (!P::has_read_wmask) return false;        // (two equations write one group, or > 64 equations: the compiler target says so)
     for (int k = 0; k < P::n_writes; k++) {
         const int gw = P::writes[k];
         unsigned long long mine = 0;
