@@ -30,6 +30,20 @@ void part(const char* name, bool first) {
            B16::lds_bytes, B16::ring_reads(), B16::XOVER, B8h::lds_bytes, B8h::ring_reads(), B8::lds_bytes, B8::ring_reads());
     clusters<P, 2>(", ");
     clusters<P, 4>(", ");
+    // the part lifted to one x plane (ykh_lift2d.hpp: what a 2-D solution's parts are given to the 3-D kernel families as)
+    printf(", \"lift2d_shape\": %d", (int)lift2d_shape<P>());
+    if constexpr (lift2d_shape<P>()) {
+        typedef Lift2D<P> L;
+        typedef BoxCfg<L, VZ, 32, 16, 1> LB;
+        int max_dy = 0, max_dz = 0, nonzero_dx = 0;
+        for (int i = 0; i < L::n_reads; i++) {
+            nonzero_dx += L::reads[i].dx != 0;
+            if (L::reads[i].dy > max_dy) max_dy = L::reads[i].dy;
+            if (L::reads[i].dz > max_dz) max_dz = L::reads[i].dz;
+        }
+        printf(", \"lifted\": {\"reads\": %d, \"nonzero_dx\": %d, \"max_dy\": %d, \"max_dz\": %d, \"mixed\": %d, \"box_eligible\": %d, \"box_128x16\": {\"lds\": %zu, \"ring_reads\": %d, \"xover\": %d}}",
+               L::n_reads, nonzero_dx, max_dy, max_dz, count_mixed<L>(), (int)box_eligible<L>(), LB::lds_bytes, LB::ring_reads(), LB::XOVER);
+    }
     printf("}");
 }
 int main() {

@@ -89,6 +89,21 @@ GENERIC_CASES = [
     ("test_stages_2d_40x36_s2", "test_stages_2d", (40, 36), 2),
     ("test_stream_1d_96_s2", "test_stream_1d", (96,), 2),
     ("test_stream_2d_40x36_s2", "test_stream_2d", (40, 36), 2),
+    # round 6: the 2-D solutions on grids of several tiles of the lifted vector kernels (csrc/ykh_lift2d.hpp: 256 x 4 and 64 x 16 points
+    # per workgroup, plane-ring tiles of 128 x 16): 40 x 520 = 10 / 3 tiles across, ragged in both dims
+    ("wave2d_40x520_s3", "wave2d", (40, 520), 3),
+    ("swe2d_40x520_s4", "swe2d", (40, 520), 4,
+     {"u": (0.0, 0.1), "v": (0.0, 0.1), "e": (0.0, 0.01), "h": (1.0, 0.1), "dt": (0.002, 0.0), "dx": (0.05, 0.0), "dy": (0.05, 0.0),
+      "inv_dx": (20.0, 0.0), "inv_dy": (20.0, 0.0), "g": (9.81, 0.0), "coriolis": (10.0, 0.0), "pe_offset": (0.5, 0.0),
+      "ti_exp": (2.0, 0.0)}),
+    ("box_filter_40x520_s2", "box_filter", (40, 520), 2),
+    ("gaussian_filter_40x520_s2", "gaussian_filter", (40, 520), 2),
+    ("test_2d_40x520_s2", "test_2d", (40, 520), 2),
+    ("test_boundary_2d_40x520_s3", "test_boundary_2d", (40, 520), 3),
+    ("test_scratch_2d_40x520_s2", "test_scratch_2d", (40, 520), 2),
+    ("test_stages_2d_40x520_s2", "test_stages_2d", (40, 520), 2),
+    ("test_misc_2d_40x520_s2", "test_misc_2d", (40, 520), 2),
+    ("test_stream_2d_40x520_s2", "test_stream_2d", (40, 520), 2),
     # four domain dims (TestStencils.cpp:254-273): the outermost one is a loop of launches on the GPU
     ("test_4d_8x10x12x14_s2", "test_4d", (8, 10, 12, 14), 2),
     # reverse-time stencil A(t-1) = f(A(t)) (TestStencils.cpp:510-518), driven as run_solution(0, -2): steps descend

@@ -60,3 +60,27 @@ def test_equation_clusters_tables(tmp_path):
     # tti's two equations read each other's var (u and v, at other step offsets: the step slots alias): not separable
     tti = tables(tmp_path, "tti")["part_1"]
     assert tti["k2"]["legal"] == 0
+
+
+def test_partial_dim_tables_at_offsets_are_legal_on_the_plane_ring_kernel(tmp_path):
+    """round 6: groups read at an offset may be vars over a SUBSET of the domain dims (kind 4: loaded through their own strides where
+    used, never given a ring); written groups still have to be full.  test_partial_3d (TestStencils.cpp): A and H get rings
+    (9 reads each), the 1-D / 2-D tables B .. G, K, L count as served -- 59 of its 79 reads were what kept it on the point kernels."""
+    p = tables(tmp_path, "test_partial_3d")["part_1"]
+    assert (p["reads"], p["box_eligible"]) == (79, 1) and p["mixed"] > 8
+    assert 2 * p["box_128x16"]["ring_reads"] >= p["reads"] and p["box_128x16"]["lds"] <= 160 * 1024
+    assert p["box_128x16"]["ring_reads"] >= 18 + 50
+
+
+def test_two_d_parts_lift_to_one_plane_of_the_three_d_families(tmp_path):
+    """ykh_lift2d.hpp: a 2-D part's reads (d0, d1, 0) become (0, d0, d1) -- one x plane, d1 along the lanes"""
+    w = tables(tmp_path, "wave2d")
+    for name, p in w.items():
+        assert p["lift2d_shape"] == 1, name
+        assert p["lifted"]["reads"] == p["reads"] and p["lifted"]["nonzero_dx"] == 0, name
+    bf = tables(tmp_path, "box_filter")["part_1"]
+    # the image filters read a dense 2-D neighbourhood: mixed reads in the lifted (y, z) plane -> the plane-ring kernel on ONE plane
+    assert bf["lifted"]["mixed"] > 8 and bf["lifted"]["box_eligible"] == 1 and bf["lifted"]["box_128x16"]["xover"] == 1
+    assert bf["lifted"]["box_128x16"]["ring_reads"] == bf["reads"]
+    # a 3-D part with z offsets is not a lifted shape
+    assert tables(tmp_path, "cube")["part_1"]["lift2d_shape"] == 0

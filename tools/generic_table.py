@@ -105,11 +105,14 @@ def markdown(recs, title):
            "per-step HIP events, default options; `families` = kernel family of every part (`starlin` / `march` = marching kernels with a",
            "register x-queue, `box` = marching kernel with an LDS ring of planes (box / plane neighbourhoods), `star25d` = 2.5-D LDS slab,",
            "`vecpt` = 16-byte vector point kernel, `naive` = one point per thread).", "",
-           "| solution | size | parts | step ms | Gpoints/s | compulsory GB/s | frac | families | worst part (frac) |",
-           "|---|---|---|---|---|---|---|---|---|"]
+           "`+ scratch` = the same with the scratch arrays counted: on the GPU a scratch var is a whole device array that one part writes and",
+           "the next reads (the reference keeps it in a per-thread cache block), so a chain of scratch parts is that many more sweeps --",
+           "what a solution like swe2d (65 parts per step, 61 of them scratch parts) really moves.", "",
+           "| solution | size | parts | step ms | Gpoints/s | compulsory GB/s | frac | + scratch | families | worst part (frac) |",
+           "|---|---|---|---|---|---|---|---|---|---|"]
     for r in recs:
         if "error" in r:
-            out.append(f"| {r['stencil']} | | | | | | | | {r['error'][:80]} |")
+            out.append(f"| {r['stencil']} | | | | | | | | | {r['error'][:80]} |")
             continue
         fams = {}
         for p in r["parts"]:
@@ -117,7 +120,7 @@ def markdown(recs, title):
         timed = [p for p in r["parts"] if p["frac"] is not None and p["points"] * 8 >= max(q["points"] for q in r["parts"])]
         worst = min(timed, key=lambda p: p["frac"]) if timed else None
         out.append(f"| {r['stencil']} | {'x'.join(str(n) for n in r['size'])} | {len(r['parts'])} | {r['step_ms']} | {r['gpoints_per_s']} | {r['compulsory_gbs']} | "
-                   f"**{r['frac']}** | {', '.join(f'{k} x{v}' if v > 1 else k for k, v in sorted(fams.items()))} | "
+                   f"**{r['frac']}** | {round((r['compulsory_bytes_per_step'] + r.get('scratch_bytes_per_step', 0)) / (r['step_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)} | {', '.join(f'{k} x{v}' if v > 1 else k for k, v in sorted(fams.items()))} | "
                    + (f"{worst['part']} `{worst['name']}` on `{worst['kernel']}` ({worst['frac']}; {worst.get('reads_per_point', '?')} reads + "
                       f"{worst.get('writes_per_point', '?')} writes per point over {worst['arrays_read']} + {worst['arrays_written']} arrays, "
                       f"{worst['fp_ops_per_point']} flops, loads at {worst.get('load_rate_tbs', '?')} TB/s)" if worst else "") + " |")
@@ -133,7 +136,13 @@ def main():
     ap.add_argument("--ramp-secs", dest="ramp_secs", type=float, default=1.5, help="seconds of untimed stepping before the timed steps (0: the round-5 protocol)")
     ap.add_argument("--opts", default="")
     ap.add_argument("--tag", default="table")
-    args = ap.parse_args()
+    # yask options start with '-': hand "--opts '-hip_variant X'" to argparse as "--opts=-hip_variant X"
+    argv = sys.argv[1:]
+    for i in range(len(argv) - 1):
+        if argv[i] == "--opts":
+            argv[i:i + 2] = ["--opts=" + argv[i + 1]]
+            break
+    args = ap.parse_args(argv)
     import __graft_entry__ as G
     names = args.only or [s for s in G.STENCILS if s not in ("3axis_r1", "wave2d_f64")] + ["3axis_r1", "wave2d_f64"]
     n3 = args.size3

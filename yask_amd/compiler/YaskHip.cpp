@@ -500,6 +500,7 @@ namespace yask {
         map<string, int> part_idx;
         vector<pair<string, vector<int>>> stages;
         int stage_no = 0;
+        int max_mixed_reads = 0;         // over the parts: distinct reads with two or more non-zero domain offsets (box / plane neighbourhoods)
         for (auto& st : _eq_stages.get_all()) {
             vector<int> members;
             for (auto& part : st->get_parts()) {
@@ -512,6 +513,11 @@ namespace yask {
                 if (em.failed)
                     THROW_YASK_EXCEPTION("the 'cdna4_hip' target cannot render part '" + pname + "' of solution '" +
                                          sname + "': " + em.fail_why);
+                {
+                    int mixed = 0;
+                    for (auto& r : em.reads) mixed += ((r.d[0] != 0) + (r.d[1] != 0) + (r.d[2] != 0)) >= 2;
+                    if (mixed > max_mixed_reads) max_mixed_reads = mixed;
+                }
 
                 // sub-domain / step conditions: rendered as predicates over the indices.
                 string cond_code = "true", step_cond_code = "true";
@@ -696,6 +702,11 @@ namespace yask {
               "// part list for the kernel registry (stencil_<name>.hip)\n#define YKH_FOR_EACH_PART(M)";
         for (auto& p : part_names) os << " M(" << p << ")";
         os << "\n\n}  // namespace ykh_gen_" << c_ident(sname) << "\n";
+        // A build hint, read by csrc/Makefile (not by C++ code): the largest number of mixed-offset reads in one part.  Above 8 (MAX_MIXED,
+        // csrc/ykh_march.hpp) the registry gives the part plane-ring shapes whose inner loops are long chains of fp32 additions; for
+        // those solutions the build adds a second translation unit compiled WITHOUT packed fp32 instructions (v_pk_add_f32 occupies the
+        // VALU ~10 cycles per wave against 4 for v_add_f32) whose shapes take part in prepare_solution()'s timing as "_np" twins.
+        os << "\n// ykh-build-hint: max-mixed-reads " << max_mixed_reads << "\n";
     }
 
 } // namespace yask.

@@ -9,6 +9,7 @@
 // stencil_ssg.hip) list more tile shapes for the hot-path stencils.
 #include YKH_GEN_HEADER
 #include "ykh_stencil_tu.hpp"
+#include <deque>
 
 namespace ykh {
 
@@ -22,6 +23,79 @@ constexpr bool starlin_eligible() {
         return P::n_groups <= 16;
     }
 }
+
+// The plane-ring shapes of a part (ykh_box.hpp) -- one list for the two translation units that register them: this one, and (for
+// solutions whose generated header carries the build hint "max-mixed-reads" > MAX_MIXED, csrc/Makefile) a second one compiled WITHOUT
+// packed fp32 instructions, where Q = NoPk<P> gives every kernel a symbol of its own and the shapes get the suffix "_np".  Whether a
+// chain of fp32 additions runs faster as v_pk_add_f32 (~10 VALU cycles per wave) or as two v_add_f32 (4 each) depends on the part
+// (cube, 3axis_with_diags, tti: plain adds; 3plane: packed; profiles/r5_box): prepare_solution()'s timing decides per part -- there is
+// no list of solution names in the build any more.
+template <class P>
+struct NoPk : P {};
+inline const char* keep_name(const std::string& n) {
+    static std::deque<std::string> names;          // (deque: pointers stay valid)
+    names.push_back(n);
+    return names.back().c_str();
+}
+template <class Q>
+void add_box_family(PartImpl& p, const char* suffix, bool set_default) {
+    typedef typename Q::real_t T;
+    constexpr int VZ = 16 / (int)sizeof(T);
+    const size_t first = p.variants.size();
+    // box / plane neighbourhoods (more mixed-offset reads than the marching kernel prefetches): planes in an LDS ring
+    // (ykh_box.hpp), for as many groups as the budget holds -- registered where the rings serve at least half of the reads.
+    // Tile 128 x 16 points (fp32; 16-byte lanes): 512 threads with one row each, or 256 threads with two rows each evaluated as one
+    // wide vector (shared LDS rows are loaded once; needs ~230 VGPRs); _p2 = planes requested two iterations ahead; _w1 = one
+    // wave per SIMD with the whole register file, for parts like tti (340 VGPRs on any kernel).  prepare_solution() times them.
+    if constexpr (box_eligible<Q>() && count_mixed<Q>() > MAX_MIXED) {
+        constexpr int TZL = 32;          // (z tile = 32 lanes of 16 bytes)
+        if constexpr (2 * BoxCfg<Q, VZ, TZL, 16, 1>::ring_reads() >= Q::n_reads) {
+            p.variants.push_back(box_variant<Q, VZ, TZL, 16, 1, 2, 1>());
+            if (set_default) p.default_variant = (int)p.variants.size() - 1;
+            p.variants.push_back(box_variant<Q, VZ, TZL, 16, 1, 2, 1 | 4>());
+            p.variants.push_back(box_variant<Q, VZ, TZL, 8, 2, 2, 1>());
+            p.variants.push_back(box_variant<Q, VZ, TZL, 8, 2, 2, 1 | 4>());
+        }
+        if constexpr (2 * BoxCfg<Q, VZ, TZL, 8, 1, 80>::ring_reads() >= Q::n_reads && Q::n_reads > 130)
+            p.variants.push_back(box_variant<Q, VZ, TZL, 8, 1, 1, 1 | 4, 80>());
+        // where the 128 x 16 tile leaves groups without a ring, the half-height tile holds more of them in the same LDS
+        if constexpr (BoxCfg<Q, VZ, TZL, 8, 1>::ring_reads() > BoxCfg<Q, VZ, TZL, 16, 1>::ring_reads() &&
+                      2 * BoxCfg<Q, VZ, TZL, 8, 1>::ring_reads() >= Q::n_reads) {
+            p.variants.push_back(box_variant<Q, VZ, TZL, 8, 1, 2, 1 | 4>());
+            if constexpr (Q::n_reads > 130) p.variants.push_back(box_variant<Q, VZ, TZL, 8, 1, 1, 1 | 4>());
+            // ... and with 8-byte lanes (two points per thread) such a part fits 256 VGPRs without spilling: 512 threads, two waves
+            // per SIMD where the 16-byte-lane shape above runs one (tti: 251 VGPRs, no scratch; 256 + 68 B without packed fp32)
+            if constexpr (Q::n_reads > 130 && VZ == 4) p.variants.push_back(box_variant<Q, 2, 64, 8, 1, 2, 1 | 4>());
+        }
+        // parts that read small tables over a subset of the domain dims at offsets (kind 4; test_partial_3d: 59 of 79 reads): every such
+        // read is live in registers from its load to its use -- with 16-byte lanes 950+ bytes of scratch per thread; 8-byte lanes halve it
+        if constexpr (box_has_tables<Q>() && VZ == 4) {
+            p.variants.push_back(box_variant<Q, 2, 64, 8, 1, 2, 1 | 4>());
+            // ... or one wave per SIMD with the whole register file (16-byte lanes, 128 x 8 tile: no scratch)
+            p.variants.push_back(box_variant<Q, VZ, 32, 8, 1, 1, 1 | 4>());
+        }
+        // (the no-packed unit also twins the vector point kernel: tti's ran 8.29 -> 5.39 ms without packed adds)
+        if (suffix[0]) p.variants.push_back(vecpt_variant<Q, VZ, 64, 4, 1>());
+    }
+    if (suffix[0])
+        for (size_t i = first; i < p.variants.size(); i++) p.variants[i].name = keep_name(std::string(p.variants[i].name) + suffix);
+}
+
+#ifdef YKH_NOPK_TU
+// ---- the second translation unit of a solution with box / plane neighbourhoods: compiled with -target-feature -packed-fp32-ops
+template <class P>
+void add_np_part(PartImpl& p, int ndd) {
+    if (ndd == 3) add_box_family<NoPk<P>>(p, "_np", false);
+}
+void ykh_add_np_variants(SolnImpl& s, int ndd) {
+    using namespace YKH_GEN_NS;
+    int pi = 0;
+#define YKH_ADD_PART(PART) add_np_part<PART>(s.parts[pi++], ndd);
+    YKH_FOR_EACH_PART(YKH_ADD_PART)
+#undef YKH_ADD_PART
+}
+#else
+void ykh_add_np_variants(SolnImpl& s, int ndd);       // (defined in the no-packed unit when the build has one: YKH_HAS_NOPK_TU)
 
 template <class P>
 void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
@@ -61,32 +135,7 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
                     p.variants.push_back(march_variant<P, VZ, 32, 16, 2, 1, false, 1, 3 | 4>());
                 }
             }
-            // box / plane neighbourhoods (more mixed-offset reads than the marching kernel prefetches): planes in an LDS ring
-            // (ykh_box.hpp), for as many groups as the budget holds -- registered where the rings serve at least half of the reads.
-            // Tile 128 x 16 points (fp32; 16-byte lanes): 512 threads with one row each, or 256 threads with two rows each evaluated as one
-            // wide vector (shared LDS rows are loaded once; needs ~230 VGPRs); _p2 = planes requested two iterations ahead; _w1 = one
-            // wave per SIMD with the whole register file, for parts like tti (340 VGPRs on any kernel).  prepare_solution() times them.
-            if constexpr (box_eligible<P>() && count_mixed<P>() > MAX_MIXED) {
-                constexpr int TZL = 32;          // (z tile = 32 lanes of 16 bytes)
-                if constexpr (2 * BoxCfg<P, VZ, TZL, 16, 1>::ring_reads() >= P::n_reads) {
-                    p.variants.push_back(box_variant<P, VZ, TZL, 16, 1, 2, 1>());
-                    p.default_variant = (int)p.variants.size() - 1;
-                    p.variants.push_back(box_variant<P, VZ, TZL, 16, 1, 2, 1 | 4>());
-                    p.variants.push_back(box_variant<P, VZ, TZL, 8, 2, 2, 1>());
-                    p.variants.push_back(box_variant<P, VZ, TZL, 8, 2, 2, 1 | 4>());
-                }
-                if constexpr (2 * BoxCfg<P, VZ, TZL, 8, 1, 80>::ring_reads() >= P::n_reads && P::n_reads > 130)
-                    p.variants.push_back(box_variant<P, VZ, TZL, 8, 1, 1, 1 | 4, 80>());
-                // where the 128 x 16 tile leaves groups without a ring, the half-height tile holds more of them in the same LDS
-                if constexpr (BoxCfg<P, VZ, TZL, 8, 1>::ring_reads() > BoxCfg<P, VZ, TZL, 16, 1>::ring_reads() &&
-                              2 * BoxCfg<P, VZ, TZL, 8, 1>::ring_reads() >= P::n_reads) {
-                    p.variants.push_back(box_variant<P, VZ, TZL, 8, 1, 2, 1 | 4>());
-                    if constexpr (P::n_reads > 130) p.variants.push_back(box_variant<P, VZ, TZL, 8, 1, 1, 1 | 4>());
-                    // ... and with 8-byte lanes (two points per thread) such a part fits 256 VGPRs without spilling: 512 threads, two waves
-                    // per SIMD where the 16-byte-lane shape above runs one (tti: 251 VGPRs, no scratch; 256 + 68 B without packed fp32)
-                    if constexpr (P::n_reads > 130 && VZ == 4) p.variants.push_back(box_variant<P, 2, 64, 8, 1, 2, 1 | 4>());
-                }
-            }
+            add_box_family<P>(p, "", true);       // plane-ring shapes for box / plane neighbourhoods (above)
             // big bundles (fsg: 12 and 24 equations, 296 / 435 reads): the part as K clusters of equations, one launch each
             // (ykh_subpart.hpp) -- on the point kernel (a cluster needs a third of the registers: three waves per SIMD instead
             // of one) and, where every cluster's slabs fit the LDS, on the marching kernel.
@@ -123,6 +172,25 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
                 }
             }
         }
+    } else if (ndd == 4) {
+        // four domain dims (test_4d): the outermost one is a loop of launches with shifted base pointers (Solution::launch_part), each
+        // launch sweeps the inner three -- with the vector point kernel too since round 6 (was: scalar point kernel only)
+        p.variants.push_back(vecpt_variant<P, VZ, 64, 4, 1>());
+        p.default_variant = (int)p.variants.size() - 1;
+    } else if (ndd == 2) {
+        // two domain dims: the 3-D families on the part lifted to one x plane (ykh_lift2d.hpp) -- 16-byte vectors along the unit-stride
+        // dim instead of the scalar point kernel's 4-byte loads (wave2d, swe2d: 15 / 65 full-domain sweeps per step); parts with many
+        // mixed-offset reads (image filters) also get the plane-ring kernel, which on one plane is an LDS-tiled 2-D kernel
+        if constexpr (lift2d_shape<P>()) {
+            typedef Lift2D<P> L;
+            auto lifted = [&](KernelVariant kv) { kv.lift2d = true; p.variants.push_back(kv); };
+            lifted(vecpt_variant<L, VZ, 64, 4, 1>());
+            p.default_variant = (int)p.variants.size() - 1;
+            lifted(vecpt_variant<L, VZ, 16, 16, 1>());          // (64 x 16-point tile: thin boxes, short rows)
+            if constexpr (box_eligible<L>() && count_mixed<L>() > MAX_MIXED) {
+                if constexpr (2 * BoxCfg<L, VZ, 32, 16, 1>::ring_reads() >= L::n_reads) lifted(box_variant<L, VZ, 32, 16, 1, 2, 1>());
+            }
+        }
     }
     s.parts.push_back(p);
 }
@@ -140,8 +208,12 @@ const SolnImpl& ykh_solution_impl() {
 #define YKH_ADD_PART(PART) add_part<PART>(s, &parts[pi++], ndd);
         YKH_FOR_EACH_PART(YKH_ADD_PART)
 #undef YKH_ADD_PART
+#ifdef YKH_HAS_NOPK_TU
+        ykh_add_np_variants(s, ndd);
+#endif
         return s;
     }();
     return impl;
 }
+#endif   // YKH_NOPK_TU
 }  // namespace ykh

@@ -59,18 +59,31 @@ constexpr int count_mixed() {
     }
     return n;
 }
-// As for the marching kernel: groups read at an offset and written groups are vars over all domain dims (shared strides / pads).
+// Written groups are vars over all domain dims (shared strides / pads).  Groups read at an offset may be vars over a SUBSET of the
+// domain dims since round 6 (test_partial_3d: 1-D and 2-D coefficient tables read at offsets): they never get a ring -- a table
+// that lacks a dim is small and stays in the L1 / L2 -- and are loaded where they are used through their own strides (kind 4).
 template <class P>
 constexpr bool box_eligible() {
     for (int g = 0; g < P::n_groups; g++) {
         const BoxShape s = box_shape<P>(g);
-        if ((s.offs || s.written) && !P::group_full[g]) return false;
+        if (s.written && !P::group_full[g]) return false;
     }
     return P::n_groups <= MAX_GROUPS;
 }
 
+// some group of the part is a var over a subset of the domain dims that is read at an offset (kind 4 of BoxTab)
+template <class P>
+constexpr bool box_has_tables() {
+    for (int g = 0; g < P::n_groups; g++) {
+        const BoxShape s = box_shape<P>(g);
+        if (s.offs && !P::group_full[g]) return true;
+    }
+    return false;
+}
+
 struct BoxTab {
-    int kind[MAX_GROUPS];               // 0: not read, 1: centre only (prefetch register), 2: ring of planes in the LDS, 3: global loads where used
+    int kind[MAX_GROUPS];               // 0: not read, 1: centre only (prefetch register), 2: ring of planes in the LDS, 3: global loads where used,
+                                        // 4: a var over a subset of the domain dims read at offsets: global loads through its own strides
     int xlo[MAX_GROUPS], nx[MAX_GROUPS], nr[MAX_GROUPS];      // planes x+xlo .. x+xlo+nx-1 are live; nr = nx + 1 slots
     int yl[MAX_GROUPS], zlv[MAX_GROUPS], lp[MAX_GROUPS], lpv[MAX_GROUPS], lrows[MAX_GROUPS], plane[MAX_GROUPS];
     int roff[MAX_GROUPS + 1];           // element offset of the group's ring
@@ -93,7 +106,7 @@ struct BoxCfg {
         for (int i = 0; i < P::n_reads; i++) nreads[P::reads[i].g]++;
         for (int g = 0; g < NG; g++) {
             const BoxShape s = box_shape<P>(g);
-            t.kind[g] = !s.any ? 0 : (s.offs ? 3 : 1);
+            t.kind[g] = !s.any ? 0 : (s.offs ? (P::group_full[g] ? 3 : 4) : 1);
             if (t.kind[g] != 3) continue;
             t.xlo[g] = s.xlo; t.nx[g] = s.xhi - s.xlo + 1; t.nr[g] = t.nx[g] + 1;
             t.yl[g] = -s.ylo;
@@ -130,7 +143,8 @@ struct BoxCfg {
     static constexpr BoxTab tab = make();
     static constexpr int RING_TOT = tab.roff[NG], NVTOT = tab.voff[NG], NSTOT = tab.soff[NG];
     static constexpr size_t lds_bytes = sizeof(T) * (size_t)(RING_TOT > 0 ? RING_TOT : 1);
-    static constexpr int ring_reads() { int n = 0; for (int i = 0; i < P::n_reads; i++) if (tab.kind[P::reads[i].g] == 2) n++; return n; }
+    // reads served from the LDS rings -- or from small tables that lack a dim (kind 4: L1-resident); what is left are the kind-3 reads
+    static constexpr int ring_reads() { int n = 0; for (int i = 0; i < P::n_reads; i++) if (tab.kind[P::reads[i].g] == 2 || tab.kind[P::reads[i].g] == 4) n++; return n; }
     static constexpr int max_nx() { int m = 1; for (int g = 0; g < NG; g++) if (tab.kind[g] == 2 && tab.nx[g] > m) m = tab.nx[g]; return m; }
     static constexpr int XOVER = max_nx();      // a block fills its rings before its first plane
 };
@@ -183,6 +197,22 @@ struct BoxAcc {
             return rows([&](auto jc) -> V1 {
                 constexpr int j = decltype(jc)::value;
                 const T* p = px + (idx_t)clampi(y + j + DY, a.ay0, a.ay1 - 1) * a.sy;
+                if constexpr (e == 0) return ldv<V1>(p + zl);
+                else return zshiftn<T, VZ, e>(ldv<V1>(p + zl), ldv<V1>(p + zh));
+            });
+        } else if constexpr (C::tab.kind[G] == 4) {
+            // a var over a subset of the domain dims (its strides are 0 in the dims it lacks), read at an offset: every var shares the
+            // solution's pads in the dims it has (Var::compute_geometry), so the clamps of the shared layout hold for it too
+            const T* px = (const T*)a.ptr[G] + (idx_t)clampi(x + DX, a.ax0, a.ax1 - 1) * a.gsx[G];
+            if (a.gsz[G] == 0)          // no unit-stride dim: one value per row (uniform branch)
+                return rows([&](auto jc) -> V1 {
+                    constexpr int j = decltype(jc)::value;
+                    return V1(px[(idx_t)clampi(y + j + DY, a.ay0, a.ay1 - 1) * a.gsy[G]]);
+                });
+            const int zl = clampi(z0 + qq * VZ, a.az0, a.az1 - VZ), zh = clampi(z0 + (qq + 1) * VZ, a.az0, a.az1 - VZ);
+            return rows([&](auto jc) -> V1 {
+                constexpr int j = decltype(jc)::value;
+                const T* p = px + (idx_t)clampi(y + j + DY, a.ay0, a.ay1 - 1) * a.gsy[G];
                 if constexpr (e == 0) return ldv<V1>(p + zl);
                 else return zshiftn<T, VZ, e>(ldv<V1>(p + zl), ldv<V1>(p + zh));
             });

@@ -58,6 +58,9 @@ struct KernelVariant {
     // cluster variants ("c<K>_*": K kernels behind one launch function): the kernels of clusters 1 .. K-1 (func is cluster 0's)
     const void* more_funcs[7] = {};
     int n_more_funcs = 0;
+    // a 3-D kernel family instantiated on Lift2D<part> (ykh_lift2d.hpp): the part has two domain dims (d0, d1), the kernel sees them
+    // as (y, z) of one x plane; Solution::launch_part_variant() moves the box and the PartArgs up one dim before the launch
+    bool lift2d = false;
 };
 // bytes of scratch (private segment) per thread of a variant's kernel(s) -- the maximum over the kernels of a cluster variant;
 // > 0 means hipcc spilled registers
@@ -525,6 +528,7 @@ public:
     // internals used by ykh_halo.cpp / tuner
     void setup_rank();
     void launch_part(int part, idx_t t, const Box& box, hipStream_t s);
+    Box scratch_grown_box(int part, const Box& box) const;
     bool launching_interior = false;      // set by launch_interior() of an overlapped exchange
     bool launching_exterior = false;      // set by run() around the exterior slabs of a decomposed run (thin-slab kernel choice)
     void launch_part_variant(int part, int variant, idx_t xchunk, idx_t t, const Box& box_in, hipStream_t s);

@@ -508,7 +508,11 @@ void Solution::prepare() {
         int* dbb = nullptr;
         for (size_t p = 0; p < impl.parts.size(); p++) {
             const PartImpl& pi = impl.parts[p];
-            if (!pi.cond_bb || !pi.meta->has_domain_cond || pi.meta->is_scratch) continue;
+            // (scratch parts too, since round 6: swe2d / wave2d are 65 / 15 parts per step, all but four of them scratch parts under
+            //  a condition -- without a box each swept its whole grown box on the scalar point kernel, predicate per point, 31 of
+            //  swe2d's to write a boundary strip.  Their box is found over the rank box GROWN by the halos of the scratch vars they write,
+            //  which is what launch_part() evaluates them over.)
+            if (!pi.cond_bb || !pi.meta->has_domain_cond) continue;
             if (!dbb) YKH_HIP(hipMalloc(&dbb, 8 * sizeof(int)));
             const int init[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0};
             YKH_HIP(hipMemcpyAsync(dbb, init, sizeof(init), hipMemcpyHostToDevice, compute_stream));
@@ -525,6 +529,7 @@ void Solution::prepare() {
                     if (hi[d]) rb.hi[d] += wf_ext_[d];
                 }
             }
+            if (pi.meta->is_scratch) rb = scratch_grown_box((int)p, rb);
             PartArgs a;
             fill_part_args((int)p, 0, rb, a);
             pi.cond_bb(a, point_grid(rb, a.lane_dim), dbb, compute_stream);
@@ -545,7 +550,7 @@ void Solution::prepare() {
             // not solid: the list of full boxes, when the region is a handful of them (awp's free-surface planes minus their
             // sponge margins, fsg_abc's 20-point shell = 6 boxes); the fast kernels then run box by box instead of the point
             // kernel sweeping the bounding box with a predicate (fsg_abc 512^3: 30 ms for the stress part's shell)
-            if (!part_bb_solid[p] && count > 0 && ndd == 3 && !has_outer && !wf_multi() && pi.cond_profile) {
+            if (!part_bb_solid[p] && count > 0 && ndd == 3 && !has_outer && !wf_multi() && pi.cond_profile && !pi.meta->is_scratch) {
                 std::vector<Box> boxes;
                 if (find_part_boxes((int)p, bb, count, boxes)) part_boxes[p] = std::move(boxes);
             }
@@ -825,6 +830,19 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
     const KernelVariant& kv = impl.parts[part].variants[variant];
     PartArgs a;
     fill_part_args(part, t, box, a);
+    if (kv.lift2d) {
+        // a 2-D part on a 3-D kernel family (ykh_lift2d.hpp): (d0, d1) -> (y, z) of ONE x plane.  Everything that is indexed by
+        // domain dim moves up one place; base pointers stay (they address local element (0, 0) either way).
+        for (int g = 0; g < impl.parts[part].meta->n_groups; g++) { a.gsz[g] = (int)a.gsy[g]; a.gsy[g] = a.gsx[g]; a.gsx[g] = 0; }
+        a.sy = a.sx; a.sx = 0;
+        a.z0 = a.y0; a.z1 = a.y1; a.y0 = a.x0; a.y1 = a.x1; a.x0 = 0; a.x1 = 1;
+        a.az0 = a.ay0; a.az1 = a.ay1; a.ay0 = a.ax0; a.ay1 = a.ax1; a.ax0 = 0; a.ax1 = 1;
+        a.ofs_z = a.ofs_y; a.ofs_y = a.ofs_x; a.ofs_x = 0;
+        a.glast_z = a.glast_y; a.glast_y = a.glast_x; a.glast_x = 0;
+        a.dom_z1 = a.dom_y1; a.dom_y1 = a.dom_x1; a.dom_x1 = 1;
+        a.lane_dim = 2;
+        box.lo[2] = box.lo[1]; box.hi[2] = box.hi[1]; box.lo[1] = box.lo[0]; box.hi[1] = box.hi[0]; box.lo[0] = 0; box.hi[0] = 1;
+    }
     if (kv.star) {
         const int vz = kv.vz > 0 ? kv.vz : 16 / elem_bytes();
         idx_t zt0 = box.lo[2] & ~(idx_t)(vz - 1);
@@ -875,6 +893,9 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
                     Box sub = box;
                     sub.lo[1] = y0;
                     sub.hi[1] = std::min(y0 + rows * kv.ty, box.hi[1]);
+                    if (kv.lift2d) {          // (the callee lifts again: hand it the sub-box in the solution's own two dims)
+                        sub.lo[0] = sub.lo[1]; sub.hi[0] = sub.hi[1]; sub.lo[1] = sub.lo[2]; sub.hi[1] = sub.hi[2]; sub.lo[2] = 0; sub.hi[2] = 1;
+                    }
                     launch_part_variant(part, variant, xc, t, sub, s);
                 }
                 return;
@@ -954,7 +975,11 @@ void Solution::launch_part(int part, idx_t t, const Box& box_in, hipStream_t s) 
     // scratch part: evaluate over the box grown by the halo of the scratch var(s) it writes, so that the
     // parts reading them at offsets find every value (the reference does this per micro-block,
     // src/kernel/lib/stencil_calc.cpp:40-289; here the scratch var is a whole device array)
-    const Box& box = box_in;
+    launch_part_variant(part, part_variant[part], part_xchunk[part], t, scratch_grown_box(part, box_in), s);
+}
+// the box a scratch part is evaluated over when its consumers run over `box`: grown by the halos of the scratch var(s) it writes
+Box Solution::scratch_grown_box(int part, const Box& box) const {
+    const PartMeta& pm = *impl.parts[part].meta;
     Box b = box;
     for (int w = 0; w < pm.n_writes; w++) {
         const AccessGroup& ag = pm.groups[pm.writes[w]];
@@ -966,7 +991,7 @@ void Solution::launch_part(int part, idx_t t, const Box& box_in, hipStream_t s) 
                         b.hi[d] = std::max(b.hi[d], box.hi[d] + v->halo_r[d]);
                     }
     }
-    launch_part_variant(part, part_variant[part], part_xchunk[part], t, b, s);
+    return b;
 }
 
 // ------------------------------------------------------------------ run

@@ -11,6 +11,7 @@
 #include "ykh_march.hpp"
 #include "ykh_box.hpp"
 #include "ykh_subpart.hpp"
+#include "ykh_lift2d.hpp"
 #include "ykh_runtime.hpp"
 
 namespace ykh {
