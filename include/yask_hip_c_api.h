@@ -270,6 +270,13 @@ int yk_solution_get_part_bounding_box(yk_soln_h s, int part, yk_idx_t* first, yk
  * boxes (3 rank-local indices each in first / last, last inclusive) and returns their number: 0 = no list (unconditional part,
  * a condition that fills its bounding box, or one left to the point kernel's per-point predicate), -1 on error. */
 int yk_solution_get_part_full_boxes(yk_soln_h s, int part, int cap, yk_idx_t* first, yk_idx_t* last);
+/* Scratch vars on chip.  The reference evaluates scratch vars per micro-block into per-thread arrays that stay in cache
+ * (src/kernel/lib/stencil_calc.cpp:40-289); here a 2-D solution's run of scratch stages and the stage they feed can run as ONE
+ * kernel per step with the scratch vars in the LDS of a workgroup's tile (csrc/ykh_fused.hpp).  Returns the number of such fused
+ * groups the prepared solution is using (0: every part is a sweep of its own -- not legal for this solution, switched off with
+ * YASK_HIP_FUSE_SCRATCH=0, or slower in prepare_solution()'s timing); for group g < that number, info[0..5] (when non-null) =
+ * parts in it, levels-independent scratch vars, LDS slots they share, LDS bytes, tile rows, tile columns.  -1 on error. */
+int yk_solution_get_fused_groups(yk_soln_h s, int g, long long* info);
 /* Work of one stencil part, per step on this rank -- the facts the reference prints per part and stage in
  * Stage::init_work_stats (src/kernel/lib/stencil_calc.cpp:461-598: points to eval, reads / writes / est FP-ops per point, the
  * input / output var lists), plus what a bandwidth-bound GPU kernel is measured against: the COMPULSORY HBM bytes per point =

@@ -3,6 +3,7 @@
 #include YKH_GEN_HEADER
 #include "ykh_stencil_tu.hpp"
 #include <cstdio>
+#include <string>
 using namespace ykh;
 using namespace YKH_GEN_NS;
 
@@ -46,7 +47,32 @@ void part(const char* name, bool first) {
     }
     printf("}");
 }
-int main() {
+struct GenTraits {
+    typedef YKH_GEN_NS::real_t real_t;
+    static constexpr const VarMeta* vars = YKH_GEN_NS::vars;
+    static constexpr int n_vars = YKH_GEN_NS::soln.n_vars;
+};
+template <class LIST, const int* LEVEL>
+void fuse_group(int first, int last, bool first_group) {
+    typedef FusedCfg<GenTraits, LIST, LEVEL, 16, 64> C16;
+    typedef FusedCfg<GenTraits, LIST, LEVEL, 8, 64> C8;
+    int nsv = 0, max_level = 0;
+    for (int v = 0; v < GenTraits::n_vars && v < FUSED_MAX_VARS; v++) nsv += C16::tab.first[v] >= 0;
+    for (int i = 0; i < LIST::N; i++) if (LEVEL[i] > max_level) max_level = LEVEL[i];
+    printf("%s{\"fuse_group\": [%d, %d], \"parts\": %d, \"levels\": %d, \"scratch_vars\": %d, \"slots\": %d, \"parts_ok\": %d, \"halo\": [%d, %d, %d, %d], "
+           "\"lds_16x64\": %zu, \"ok_16x64\": %d, \"lds_8x64\": %zu, \"ok_8x64\": %d}",
+           first_group ? "" : ",\n", first, last, LIST::N, max_level + 1, nsv, C16::tab.n_slots, (int)C16::tab.ok, C16::tab.hl0, C16::tab.hr0, C16::tab.hl1, C16::tab.hr1,
+           C16::lds_bytes, (int)C16::ok, C8::lds_bytes, (int)C8::ok);
+}
+int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "fused") {
+        printf("[");
+        bool firstg = true;
+#define YKH_PROBE_FG(LIST, LEVEL, FIRST, LAST) fuse_group<LIST, LEVEL>(FIRST, LAST, firstg); firstg = false;
+        YKH_FOR_EACH_FUSE_GROUP(YKH_PROBE_FG)
+        printf("]\n");
+        return 0;
+    }
     printf("[");
     bool first = true;
 #define YKH_PROBE(PART) part<PART>(#PART, first); first = false;

@@ -17,6 +17,12 @@ CSRC = ROOT / "yask_amd" / "csrc"
 pytestmark = pytest.mark.skipif(not shutil.which("hipcc"), reason="no hipcc here")
 
 
+def fused_tables(tmp_path, soln):
+    tables(tmp_path, soln)
+    out = subprocess.run([str(tmp_path / f"kt_{soln}"), "fused"], capture_output=True, text=True, check=True).stdout
+    return json.loads(out)
+
+
 def tables(tmp_path, soln):
     exe = tmp_path / f"kt_{soln}"
     r = subprocess.run(["hipcc", "-O1", "-std=c++17", "--cuda-host-only", f"-I{CSRC}", f'-DYKH_GEN_HEADER="gen/{soln}_cdna4_hip.hpp"',
@@ -84,3 +90,19 @@ def test_two_d_parts_lift_to_one_plane_of_the_three_d_families(tmp_path):
     assert bf["lifted"]["box_128x16"]["ring_reads"] == bf["reads"]
     # a 3-D part with z offsets is not a lifted shape
     assert tables(tmp_path, "cube")["part_1"]["lift2d_shape"] == 0
+
+
+def test_fused_scratch_group_plans(tmp_path):
+    """csrc/ykh_fused.hpp: the compiler target lists a run of scratch stages + the stage they feed with the level of every part; the plan
+    gives every scratch var an LDS slot for its live range (first write .. last read, in levels) and re-uses slots across ranges."""
+    w = fused_tables(tmp_path, "wave2d")
+    assert len(w) == 1 and (w[0]["parts"], w[0]["levels"], w[0]["scratch_vars"], w[0]["slots"]) == (15, 3, 6, 6) and w[0]["ok_16x64"] == 1
+    assert w[0]["lds_16x64"] == 6 * (16 + 2) * (64 + 2) * 4
+    s = fused_tables(tmp_path, "swe2d")
+    assert len(s) == 1 and (s[0]["parts"], s[0]["levels"], s[0]["scratch_vars"]) == (65, 17, 39)
+    assert s[0]["slots"] <= 16 and s[0]["halo"] == [5, 4, 5, 4]            # 39 vars, a dozen alive at a time
+    assert s[0]["lds_16x64"] == s[0]["slots"] * (16 + 9) * (64 + 9) * 4 <= 160 * 1024 and s[0]["ok_16x64"] == 1
+    # a 3-D solution's scratch group is listed by the compiler target but is not a shape the 2-D kernel takes (reads with a third offset)
+    t3 = fused_tables(tmp_path, "test_scratch_3d")
+    assert len(t3) == 1 and t3[0]["parts_ok"] == 0 and t3[0]["ok_16x64"] == 0
+    assert fused_tables(tmp_path, "iso3dfd") == []

@@ -74,6 +74,7 @@ PROTOTYPES = {
     "yk_solution_get_kernel_variant_scratch_bytes": (idx_t, [_H, C.c_int, C.c_int]),
     "yk_solution_get_part_bounding_box": (C.c_int, [_H, C.c_int, C.POINTER(idx_t), C.POINTER(idx_t)]),
     "yk_solution_get_part_full_boxes": (C.c_int, [_H, C.c_int, C.c_int, C.POINTER(idx_t), C.POINTER(idx_t)]),
+    "yk_solution_get_fused_groups": (C.c_int, [_H, C.c_int, C.POINTER(C.c_longlong)]),
     "yk_solution_clear_stats": (C.c_int, [_H]),
     "yk_solution_get_step_times": (C.c_int, [_H, C.POINTER(C.c_float), C.c_int]),
     "yk_solution_get_placement_trials": (C.c_int, [_H, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int]),

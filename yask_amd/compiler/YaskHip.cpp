@@ -499,6 +499,7 @@ namespace yask {
         vector<string> part_meta;
         map<string, int> part_idx;
         vector<pair<string, vector<int>>> stages;
+        vector<bool> stage_is_scratch;
         int stage_no = 0;
         int max_mixed_reads = 0;         // over the parts: distinct reads with two or more non-zero domain offsets (box / plane neighbourhoods)
         for (auto& st : _eq_stages.get_all()) {
@@ -680,8 +681,10 @@ namespace yask {
                 part_names.push_back(pname);
                 part_meta.push_back(pm.str());
             }
-            if (!st->is_scratch() || !members.empty())
+            if (!st->is_scratch() || !members.empty()) {
                 stages.push_back({st->_get_name(), members});
+                stage_is_scratch.push_back(st->is_scratch());
+            }
             stage_no++;
         }
 
@@ -701,7 +704,39 @@ namespace yask {
            << part_names.size() << ", parts, " << stages.size() << ", stages};\n\n"
               "// part list for the kernel registry (stencil_<name>.hip)\n#define YKH_FOR_EACH_PART(M)";
         for (auto& p : part_names) os << " M(" << p << ")";
-        os << "\n\n}  // namespace ykh_gen_" << c_ident(sname) << "\n";
+        os << "\n";
+        // Fusion groups: a run of scratch stages and the stage they feed, as ONE list of part types in evaluation order, with the
+        // level (stage within the group) of every part -- parts of a level are independent, a level reads what earlier levels wrote.
+        // The runtime can evaluate such a group tile by tile with the scratch vars in the LDS (csrc/ykh_fused.hpp) instead of one
+        // sweep of the grid per part.  M(list type, level array, first stage index, last stage index).
+        {
+            ostringstream fg;
+            int ngroups = 0;
+            size_t k = 0;
+            while (k < stages.size()) {
+                size_t first = k;
+                while (k < stages.size() && stage_is_scratch[k]) k++;
+                if (k >= stages.size()) break;            // (scratch stages nobody consumes: none in practice)
+                if (k > first) {
+                    os << "typedef ykh::PartList<";
+                    bool firstp = true;
+                    ostringstream lv;
+                    for (size_t st = first; st <= k; st++)
+                        for (int pi : stages[st].second) {
+                            os << (firstp ? "" : ", ") << part_names[pi];
+                            lv << (firstp ? "" : ", ") << (st - first);
+                            firstp = false;
+                        }
+                    os << "> fuse_group_" << ngroups << ";\n"
+                       << "static constexpr int fuse_group_" << ngroups << "_level[] = {" << lv.str() << "};\n";
+                    fg << " M(fuse_group_" << ngroups << ", fuse_group_" << ngroups << "_level, " << first << ", " << k << ")";
+                    ngroups++;
+                }
+                k++;
+            }
+            os << "#define YKH_FOR_EACH_FUSE_GROUP(M)" << fg.str() << "\n";
+        }
+        os << "\n}  // namespace ykh_gen_" << c_ident(sname) << "\n";
         // A build hint, read by csrc/Makefile (not by C++ code): the largest number of mixed-offset reads in one part.  Above 8 (MAX_MIXED,
         // csrc/ykh_march.hpp) the registry gives the part plane-ring shapes whose inner loops are long chains of fp32 additions; for
         // those solutions the build adds a second translation unit compiled WITHOUT packed fp32 instructions (v_pk_add_f32 occupies the

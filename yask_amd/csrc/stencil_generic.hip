@@ -195,6 +195,13 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
     s.parts.push_back(p);
 }
 
+// the generated header's var table, for the compile-time plans of ykh_fused.hpp
+struct GenTraits {
+    typedef YKH_GEN_NS::real_t real_t;
+    static constexpr const VarMeta* vars = YKH_GEN_NS::vars;
+    static constexpr int n_vars = YKH_GEN_NS::soln.n_vars;
+};
+
 const SolnImpl& ykh_solution_impl() {
     using namespace YKH_GEN_NS;
     static const SolnImpl impl = [] {
@@ -208,6 +215,13 @@ const SolnImpl& ykh_solution_impl() {
 #define YKH_ADD_PART(PART) add_part<PART>(s, &parts[pi++], ndd);
         YKH_FOR_EACH_PART(YKH_ADD_PART)
 #undef YKH_ADD_PART
+        // 2-D solutions with scratch stages: each run of scratch stages + the stage it feeds also as ONE kernel with the scratch vars in
+        // the LDS (ykh_fused.hpp); prepare_solution() times a step both ways
+        if (ndd == 2) {
+#define YKH_ADD_FUSED(LIST, LEVEL, FIRST, LAST) add_fused_group<GenTraits, LIST, LEVEL>(s, FIRST, LAST);
+            YKH_FOR_EACH_FUSE_GROUP(YKH_ADD_FUSED)
+#undef YKH_ADD_FUSED
+        }
 #ifdef YKH_HAS_NOPK_TU
         ykh_add_np_variants(s, ndd);
 #endif

@@ -437,6 +437,19 @@ int yk_solution_get_part_full_boxes(yk_soln_h s, int part, int cap, yk_idx_t* fi
     return (int)bl.size();
     YK_CATCH(-1)
 }
+int yk_solution_get_fused_groups(yk_soln_h s, int g, long long* info) {
+    YK_TRY
+    Solution& so = S(s);
+    if (!so.prepared) YKH_THROW("get_fused_groups() called without calling prepare_solution() first");
+    if (!so.fused_on) return 0;
+    const int n = (int)so.impl.fused.size();
+    if (info && g >= 0 && g < n) {
+        const FusedGroupImpl& fg = so.impl.fused[g];
+        info[0] = fg.n_parts; info[1] = fg.n_scratch_vars; info[2] = fg.n_slots; info[3] = (long long)fg.lds_bytes; info[4] = fg.ti; info[5] = fg.tj;
+    }
+    return n;
+    YK_CATCH(-1)
+}
 int yk_solution_get_part_info(yk_soln_h s, int part, yk_part_info_t* out) {
     YK_TRY
     Solution& so = S(s);

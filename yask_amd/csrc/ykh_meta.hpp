@@ -94,6 +94,10 @@ struct BlockDesc {
 };
 enum { BLOCK_SIGNALS = 1 };
 
+// a list of part types in evaluation order (fusion groups of the generated headers, YKH_FOR_EACH_FUSE_GROUP)
+template <class... Ps>
+struct PartList { static constexpr int N = (int)sizeof...(Ps); };
+
 struct StageMeta {
     const char* name;
     int n_parts;

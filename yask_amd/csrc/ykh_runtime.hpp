@@ -115,10 +115,21 @@ struct PartImpl {
         throw std::runtime_error(std::string("no kernel variant named ") + name);
     }
 };
+// A run of scratch stages and the stage they feed as ONE kernel with the scratch vars in the LDS (ykh_fused.hpp; 2-D solutions)
+struct FusedGeom;
+struct FusedGroupImpl {
+    int first_stage = 0, last_stage = 0;      // indices into SolnMeta::stages
+    int n_parts = 0;                          // parts of those stages, in order = the kernel's PartArgs array
+    size_t lds_bytes = 0;
+    int threads = 0, ti = 0, tj = 0, n_slots = 0, n_scratch_vars = 0;
+    void (*launch)(const PartArgs* dev_args, const FusedGeom& g, unsigned grid, hipStream_t s) = nullptr;
+    const void* func = nullptr;
+};
 struct SolnImpl {
     const SolnMeta* meta;
     std::vector<PartImpl> parts;
     bool select_by_timing = false;     // prepare_solution() times the legal shapes of each part once and keeps the fastest
+    std::vector<FusedGroupImpl> fused;
 };
 // Defined once per stencil library (stencil_<name>.hip).
 const SolnImpl& ykh_solution_impl();
@@ -529,6 +540,18 @@ public:
     void setup_rank();
     void launch_part(int part, idx_t t, const Box& box, hipStream_t s);
     Box scratch_grown_box(int part, const Box& box) const;
+    // fused scratch groups (ykh_fused.hpp): usable on this solution / on for the coming steps; per group and step slot phase the
+    // device array of the parts' PartArgs (built by ensure_fused_args(), outside any stream capture)
+    int fuse_scratch_mode = -1;            // YASK_HIP_FUSE_SCRATCH: 0 off, 1 on wherever legal, -1 (default) decided by timing at prepare_solution()
+    bool fused_on = false;
+    bool fused_usable() const;
+    bool fused_ok_at(const FusedGroupImpl& fg, idx_t t) const;
+    const FusedGroupImpl* fused_group_at(int stage) const;
+    void ensure_fused_args();
+    void drop_fused_args();
+    void launch_fused(const FusedGroupImpl& fg, idx_t t, hipStream_t s);
+    std::vector<std::vector<PartArgs*>> fused_args_;      // [group][phase]
+    std::string fused_args_key_;
     bool launching_interior = false;      // set by launch_interior() of an overlapped exchange
     bool launching_exterior = false;      // set by run() around the exterior slabs of a decomposed run (thin-slab kernel choice)
     void launch_part_variant(int part, int variant, idx_t xchunk, idx_t t, const Box& box_in, hipStream_t s);

@@ -77,6 +77,7 @@ size_t variant_scratch_bytes(const KernelVariant& kv) {
 // ------------------------------------------------------------------ Solution basics
 Solution::Solution(std::shared_ptr<Env> e, const SolnImpl& im) : env(e), impl(im), meta(im.meta) {
     ordinal = env->solutions_made++;
+    if (const char* e = getenv("YASK_HIP_FUSE_SCRATCH")) fuse_scratch_mode = atoi(e);
     ndd = 0;
     for (int i = 0; i < meta->ndims; i++) {
         const DimMeta& d = meta->dims[i];
@@ -112,6 +113,7 @@ Solution::Solution(std::shared_ptr<Env> e, const SolnImpl& im) : env(e), impl(im
 Solution::~Solution() {
     drop_step_graphs();
     drop_launch_plans();
+    drop_fused_args();
     if (lockstep_dev) (void)hipFree(lockstep_dev);
     free_halo_buffers();
     vars.clear();
@@ -651,6 +653,9 @@ void Solution::prepare() {
     }
     stats = Stats();
     prepared = true;
+    // scratch stages + their consumer as one kernel (ykh_fused.hpp): on where legal unless switched off; the timing pass below
+    // (tune_variants) runs a step both ways and keeps the faster when the choice was left open
+    fused_on = fused_usable() && fuse_scratch_mode != 0;
     if (placed && placement_trials > 1) tune_placement();
     else { placement_ms.clear(); placement_chosen = 0; }
     if (env->nranks > 1) small_grid = env->max_over_ranks(small_grid ? 1 : 0) != 0;     // (local sizes may differ by rank)
@@ -666,6 +671,7 @@ void Solution::prepare() {
 void Solution::end() {
     synchronize();
     drop_step_graphs();
+    drop_fused_args();
     drop_launch_plans();
     free_halo_buffers();
     for (auto& v : vars) v->release();
@@ -1094,6 +1100,7 @@ void Solution::run(idx_t first_step, idx_t last_step) {
         }
         t += dir * g;
     }
+    if (fused_on && !multi) ensure_fused_args();          // (device tables of the fused scratch groups: never built inside a capture)
     // Launch-bound runs: the launches of a whole number of slot periods are captured once and replayed (step graphs, below).
     idx_t t_plain = first_plain;
     if (!wavefront && !multi && !step_timers && step_graph_wanted()) {
@@ -1123,6 +1130,16 @@ void Solution::run(idx_t first_step, idx_t last_step) {
     halves_in_flight_ = false;
     for (idx_t t = t_plain; !wavefront && (dir > 0 ? t <= last_step : t >= last_step); t += dir) {
         for (int st = 0; st < meta->n_stages; st++) {
+            if (fused_on && !multi) {
+                const FusedGroupImpl* fg = fused_group_at(st);
+                if (fg && fused_ok_at(*fg, t)) {
+                    // a run of scratch stages and the stage they feed: ONE launch, scratch vars in the LDS (ykh_fused.hpp)
+                    launch_fused(*fg, t, compute_stream);
+                    note_stage_written(meta->stages[fg->last_stage], t);
+                    st = fg->last_stage;
+                    continue;
+                }
+            }
             const StageMeta& sm = meta->stages[st];
             bool lo[MAX_DOMAIN_DIMS], hi[MAX_DOMAIN_DIMS];
             neighbor_sides(lo, hi);

@@ -10,6 +10,7 @@
 
 #include "ykh_runtime.hpp"
 #include "ykh_solution_internal.hpp"
+#include "ykh_fused.hpp"
 
 namespace ykh {
 
@@ -184,9 +185,103 @@ void Solution::drop_step_graphs() {
 void Solution::issue_step(idx_t t) {
     const Box rb = rank_box();
     for (int st = 0; st < meta->n_stages; st++) {
+        if (fused_on) {
+            const FusedGroupImpl* fg = fused_group_at(st);
+            if (fg && fused_ok_at(*fg, t)) {       // scratch stages + the stage they feed: one launch
+                launch_fused(*fg, t, compute_stream);
+                st = fg->last_stage;
+                continue;
+            }
+        }
         const StageMeta& sm = meta->stages[st];
         for (int k = 0; k < sm.n_parts; k++) launch_part(sm.parts[k], t, rb, compute_stream);
     }
+}
+
+// ------------------------------------------------------------------ fused scratch groups (ykh_fused.hpp)
+// Legal on this solution?  Two domain dims, one rank (a decomposed rank evaluates exterior and interior boxes part by part), no 4th
+// dim, no part whose arithmetic sees the value of the step index (the PartArgs of a group are built once per step-slot phase).
+bool Solution::fused_usable() const {
+    if (impl.fused.empty() || ndd != 2 || has_outer || env->nranks > 1 || force_scalar || !variant_override.empty()) return false;
+    for (auto* list : {&vars, &scratch_vars})          // (the kernel addresses global memory with 32-bit element offsets)
+        for (auto& v : *list)
+            if ((double)v->slot_elems * (double)std::max(1, v->nslots) >= 2147483648.0) return false;
+    return true;
+}
+// ... and at this step?  A part with a host-side step condition that is false now would have to be left out of the kernel: such a step
+// goes part by part instead.  (Device-side step conditions and the value of the step index are handled by the kernel.)
+bool Solution::fused_ok_at(const FusedGroupImpl& fg, idx_t t) const {
+    for (int st = fg.first_stage; st <= fg.last_stage; st++)
+        for (int k = 0; k < meta->stages[st].n_parts; k++) {
+            const PartMeta& pm = *impl.parts[meta->stages[st].parts[k]].meta;
+            if (pm.step_cond && !pm.step_cond(t)) return false;
+        }
+    return true;
+}
+const FusedGroupImpl* Solution::fused_group_at(int stage) const {
+    for (auto& fg : impl.fused)
+        if (fg.first_stage == stage) return &fg;
+    return nullptr;
+}
+void Solution::drop_fused_args() {
+    for (auto& g : fused_args_)
+        for (PartArgs* p : g) if (p) (void)hipFree(p);
+    fused_args_.clear();
+    fused_args_key_.clear();
+}
+// The PartArgs arrays of every group, one per phase of the step-slot period (base pointers are the only thing that changes from
+// step to step).  Rebuilt when var storage moved; never inside a stream capture (run() calls this before it captures).
+void Solution::ensure_fused_args() {
+    if (!fused_on) return;
+    std::ostringstream key;
+    for (auto& v : vars) key << v->dptr << '.' << v->nslots << '|';
+    for (auto& v : scratch_vars) key << v->dptr << '|';
+    for (int d = 0; d < MAX_API_DOMAIN_DIMS; d++) key << local_size[d] << '+' << rank_ofs[d] << ';';
+    if (key.str() == fused_args_key_ && !fused_args_.empty()) return;
+    drop_fused_args();
+    const idx_t P = slot_period();
+    const Box rb = rank_box();
+    fused_args_.resize(impl.fused.size());
+    for (size_t gi = 0; gi < impl.fused.size(); gi++) {
+        const FusedGroupImpl& fg = impl.fused[gi];
+        fused_args_[gi].assign((size_t)P, nullptr);
+        for (idx_t ph = 0; ph < P; ph++) {
+            std::vector<PartArgs> host;
+            for (int st = fg.first_stage; st <= fg.last_stage; st++)
+                for (int k = 0; k < meta->stages[st].n_parts; k++) {
+                    // the part's own box: the consuming stage's box, grown for a scratch part by the halos of what it writes, cut down to
+                    // the bounding box of its condition (prepare_solution() found it over the same grown box); nxc = "no predicate needed"
+                    const int part = meta->stages[st].parts[k];
+                    const PartMeta& pm = *impl.parts[part].meta;
+                    Box b = pm.is_scratch ? scratch_grown_box(part, rb) : rb;
+                    const bool has_bb = (size_t)part < part_has_bb.size() && part_has_bb[part];
+                    if (has_bb)
+                        for (int d = 0; d < MAX_DOMAIN_DIMS; d++) { b.lo[d] = std::max(b.lo[d], part_bb[part].lo[d]); b.hi[d] = std::min(b.hi[d], part_bb[part].hi[d]); }
+                    PartArgs a;
+                    fill_part_args(part, ph, b, a);
+                    a.nxc = (!pm.has_domain_cond || (has_bb && part_bb_solid[part])) ? 1 : 0;
+                    host.push_back(a);
+                }
+            if ((int)host.size() != fg.n_parts) YKH_THROW("fused group: part list of the generated header and the stage tables disagree");
+            YKH_HIP(hipMalloc(&fused_args_[gi][ph], host.size() * sizeof(PartArgs)));
+            YKH_HIP(hipMemcpy(fused_args_[gi][ph], host.data(), host.size() * sizeof(PartArgs), hipMemcpyHostToDevice));
+        }
+    }
+    fused_args_key_ = key.str();
+}
+void Solution::launch_fused(const FusedGroupImpl& fg, idx_t t, hipStream_t s) {
+    const size_t gi = (size_t)(&fg - impl.fused.data());
+    if (gi >= fused_args_.size()) YKH_THROW("fused group launched before its arguments were built");
+    const idx_t P = slot_period();
+    const PartArgs* dev = fused_args_[gi][(size_t)(((t % P) + P) % P)];
+    const Box rb = rank_box();
+    FusedGeom g;
+    g.i0 = (int)rb.lo[0]; g.i1 = (int)rb.hi[0]; g.j0 = (int)rb.lo[1]; g.j1 = (int)rb.hi[1];
+    g.ntj = (int)ceil_div(rb.hi[1] - rb.lo[1], (idx_t)fg.tj);
+    g.t = (long long)t;
+    const idx_t nti = ceil_div(rb.hi[0] - rb.lo[0], (idx_t)fg.ti);
+    fg.launch(dev, g, (unsigned)(nti * g.ntj), s);
+    YKH_HIP(hipGetLastError());
 }
 Solution::StepGraph* Solution::get_step_graph(idx_t t, idx_t dir, idx_t steps) {
     const std::string key = step_graph_key(t, dir, steps);
@@ -339,6 +434,27 @@ void Solution::tune_variants(bool quick, bool fresh_storage) {
         if (best_sp_v >= 0 && best_sp < 0.95 * best) { best_v = best_sp_v; best_xc = best_sp_xc; }
         part_variant[p] = best_v;
         part_xchunk[p] = best_xc;
+    }
+    // fused scratch groups (ykh_fused.hpp) against one sweep per part: a whole step each way, the faster is kept
+    if (fused_usable() && fuse_scratch_mode < 0) {
+        auto step_ms_of = [&](bool fused) -> double {
+            fused_on = fused;
+            if (fused) ensure_fused_args();
+            issue_step(0);                                       // warm-up (first launch of the kernels)
+            YKH_HIP(hipEventRecord(e0, compute_stream));
+            for (int r = 0; r < 3; r++) issue_step(1 + r);
+            YKH_HIP(hipEventRecord(e1, compute_stream));
+            YKH_HIP(hipEventSynchronize(e1));
+            float ms = 0;
+            YKH_HIP(hipEventElapsedTime(&ms, e0, e1));
+            double per = ms / 3.0;
+            if (many) per = (double)env->max_over_ranks((long long)(per * 1e6)) * 1e-6;
+            return per;
+        };
+        const double plain = step_ms_of(false), fused = step_ms_of(true);
+        fused_on = fused < plain;
+        if (env->trace) fprintf(stderr, "auto-tuner: a step with one sweep per part %.4f ms, with fused scratch groups %.4f ms -> %s\n", plain, fused,
+                                fused_on ? "fused" : "per part");
     }
     for (size_t i = 0; i < vars.size(); i++)
         if (saves[i]) {

@@ -472,6 +472,17 @@ class yk_solution:
         n = self._lib.call("yk_solution_get_part_full_boxes", self._h, int(part), cap, first, last)
         return [(list(first[3 * i:3 * i + 3]), list(last[3 * i:3 * i + 3])) for i in range(min(n, cap))]
 
+    def get_fused_groups(self):
+        """Fused scratch groups in use (csrc/ykh_fused.hpp: a run of scratch stages and the stage they feed as one kernel per step, scratch
+        vars in the LDS): [] when every part is a sweep of its own, else one dict per group."""
+        info = (C.c_longlong * 6)()
+        n = self._lib.call("yk_solution_get_fused_groups", self._h, -1, None)
+        out = []
+        for g in range(max(0, n)):
+            self._lib.call("yk_solution_get_fused_groups", self._h, g, info)
+            out.append(dict(parts=info[0], scratch_vars=info[1], lds_slots=info[2], lds_bytes=info[3], tile=(info[4], info[5])))
+        return out
+
     def get_kernel_variant_names(self, part=0):
         n = self._lib.call("yk_solution_get_num_kernel_variants", self._h, part)
         return [self._lib.call("yk_solution_get_kernel_variant_name", self._h, part, i).decode() for i in range(n)]
