@@ -50,6 +50,7 @@ void part(const char* name, bool first) {
 struct GenTraits {
     typedef YKH_GEN_NS::real_t real_t;
     static constexpr const VarMeta* vars = YKH_GEN_NS::vars;
+    static constexpr const DimMeta* dims = YKH_GEN_NS::dims;
     static constexpr int n_vars = YKH_GEN_NS::soln.n_vars;
 };
 template <class LIST, const int* LEVEL>

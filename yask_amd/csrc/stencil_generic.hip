@@ -199,6 +199,7 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
 struct GenTraits {
     typedef YKH_GEN_NS::real_t real_t;
     static constexpr const VarMeta* vars = YKH_GEN_NS::vars;
+    static constexpr const DimMeta* dims = YKH_GEN_NS::dims;
     static constexpr int n_vars = YKH_GEN_NS::soln.n_vars;
 };
 

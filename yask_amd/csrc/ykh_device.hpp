@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(256) cond_bb_kernel(const PartArgs a, int* out
     if constexpr (P::has_domain_cond) {
         if (z < a.z1 && y < a.y1 && x < a.x1) {
             NaiveAcc<P> acc{a, x, y, z, 0};
-            on = P::cond(acc);
+            on = P::cond(acc) != (a.nxc < 0);        // (nxc < 0: the points where the condition does NOT hold -- the "hole" of a ring)
         }
     }
     if (on) {

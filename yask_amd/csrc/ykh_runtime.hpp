@@ -426,6 +426,7 @@ public:
     std::vector<std::vector<Box>> part_boxes;
     bool in_part_boxes_ = false;                     // launch_part_variant is walking a part's box list
     bool find_part_boxes(int part, const Box& bb, unsigned long long count, std::vector<Box>& out);
+    std::vector<Box> part_hole;            // 2-D: the solid box of points where a ring-shaped condition does not hold (empty: none)
     bool part_needs_predicate(int part) const {      // only the point kernel evaluates the condition per point
         const PartMeta& pm = *impl.parts[part].meta;
         if (pm.has_step_cond_dev) return true;

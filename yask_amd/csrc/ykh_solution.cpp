@@ -506,6 +506,7 @@ void Solution::prepare() {
     part_has_bb.assign(impl.parts.size(), 0);
     part_bb_solid.assign(impl.parts.size(), 0);
     part_boxes.assign(impl.parts.size(), std::vector<Box>());
+    part_hole.assign(impl.parts.size(), Box{{0, 0, 0}, {0, 0, 0}});
     {
         int* dbb = nullptr;
         for (size_t p = 0; p < impl.parts.size(); p++) {
@@ -534,6 +535,7 @@ void Solution::prepare() {
             if (pi.meta->is_scratch) rb = scratch_grown_box((int)p, rb);
             PartArgs a;
             fill_part_args((int)p, 0, rb, a);
+            a.nxc = 0;
             pi.cond_bb(a, point_grid(rb, a.lane_dim), dbb, compute_stream);
             YKH_HIP(hipGetLastError());
             int out[8];
@@ -555,6 +557,41 @@ void Solution::prepare() {
             if (!part_bb_solid[p] && count > 0 && ndd == 3 && !has_outer && !wf_multi() && pi.cond_profile && !pi.meta->is_scratch) {
                 std::vector<Box> boxes;
                 if (find_part_boxes((int)p, bb, count, boxes)) part_boxes[p] = std::move(boxes);
+            }
+            // two domain dims: a condition that is a box minus a box -- the boundary ring around an interior, which is what the
+            // complement of an interior condition looks like (swe2d: 31 of its 65 parts define a scratch var on such a ring) -- is found
+            // by ONE more reduction: the bounding box and count of the points where the condition does NOT hold.  If that hole is
+            // itself solid, the valid points are at most four strips: the part runs its unpredicated kernels strip by strip, and the
+            // fused scratch kernel tests two boxes instead of evaluating a 64-bit predicate per point.
+            part_hole[p] = Box{{0, 0, 0}, {0, 0, 0}};
+            if (!part_bb_solid[p] && count > 0 && ndd == 2 && !has_outer && !wf_multi()) {
+                YKH_HIP(hipMemcpyAsync(dbb, init, sizeof(init), hipMemcpyHostToDevice, compute_stream));
+                fill_part_args((int)p, 0, bb, a);
+                a.nxc = -1;
+                pi.cond_bb(a, point_grid(bb, a.lane_dim), dbb, compute_stream);
+                YKH_HIP(hipGetLastError());
+                YKH_HIP(hipMemcpyAsync(out, dbb, sizeof(out), hipMemcpyDeviceToHost, compute_stream));
+                YKH_HIP(hipStreamSynchronize(compute_stream));
+                unsigned long long nhole;
+                std::memcpy(&nhole, &out[6], sizeof(nhole));
+                Box hole = bb;
+                for (int d = 0; d < 2; d++) { hole.lo[d] = out[d]; hole.hi[d] = out[3 + d] + 1; }
+                unsigned long long hvol = 1;
+                for (int d = 0; d < 2; d++) hvol *= (unsigned long long)std::max<idx_t>(0, hole.hi[d] - hole.lo[d]);
+                if (nhole > 0 && nhole == hvol && count + nhole == vol) {
+                    part_hole[p] = hole;
+                    std::vector<Box> strips;
+                    auto add = [&](idx_t l0, idx_t h0, idx_t l1, idx_t h1) {
+                        Box b = bb;
+                        b.lo[0] = l0; b.hi[0] = h0; b.lo[1] = l1; b.hi[1] = h1;
+                        if (!b.empty()) strips.push_back(b);
+                    };
+                    add(bb.lo[0], hole.lo[0], bb.lo[1], bb.hi[1]);          // rows before the hole
+                    add(hole.hi[0], bb.hi[0], bb.lo[1], bb.hi[1]);          // rows after it
+                    add(hole.lo[0], hole.hi[0], bb.lo[1], hole.lo[1]);      // left of it
+                    add(hole.lo[0], hole.hi[0], hole.hi[1], bb.hi[1]);      // right of it
+                    part_boxes[p] = std::move(strips);
+                }
             }
         }
         if (dbb) YKH_HIP(hipFree(dbb));
@@ -701,6 +738,7 @@ bool Solution::find_part_boxes(int part, const Box& bb0, unsigned long long tota
         YKH_HIP(hipMemcpyAsync(dbb, init, sizeof(init), hipMemcpyHostToDevice, compute_stream));
         PartArgs a;
         fill_part_args(part, 0, q, a);
+        a.nxc = 0;
         pi.cond_bb(a, point_grid(q, a.lane_dim), dbb, compute_stream);
         YKH_HIP(hipGetLastError());
         int o[8];

@@ -260,6 +260,12 @@ void Solution::ensure_fused_args() {
                     PartArgs a;
                     fill_part_args(part, ph, b, a);
                     a.nxc = (!pm.has_domain_cond || (has_bb && part_bb_solid[part])) ? 1 : 0;
+                    if (!a.nxc && (size_t)part < part_hole.size() && !part_hole[part].empty()) {
+                        // a ring: the condition holds in the box and outside the hole (prepare_solution() verified both are solid)
+                        a.nxc = 2;
+                        a.ax0 = (int)part_hole[part].lo[0]; a.ax1 = (int)part_hole[part].hi[0];
+                        a.ay0 = (int)part_hole[part].lo[1]; a.ay1 = (int)part_hole[part].hi[1];
+                    }
                     host.push_back(a);
                 }
             if ((int)host.size() != fg.n_parts) YKH_THROW("fused group: part list of the generated header and the stage tables disagree");
