@@ -1,5 +1,6 @@
 // CPU driver of csrc/ykh_boxes.hpp (tests/test_part_boxes_cpu.py): regions given as predicates over a small grid, the two reductions
 // answered by brute force; prints, per region, whether a list was found and whether it is exact (full, disjoint, covering).
+#include <algorithm>
 #include <cstdio>
 #include <functional>
 #include <string>
@@ -77,6 +78,42 @@ int main() {
     run("slanted", n, [&](long long x, long long y, long long z) { return x < y; }, false);
     run("checkerboard", n, [&](long long x, long long y, long long z) { return ((x + y + z) & 1) == 0; }, false);
     run("staircase", n, [&](long long x, long long y, long long z) { return y <= (x / 3) * 3; }, false);
+    // ---- rings of 2-D solutions (ring_strips): a 40 x 36 grid, the region known through the same two reductions
+    {
+        const long long m[2] = {40, 36};
+        auto ring = [&](const char* name, auto in) {
+            B bb{{m[0], m[1], 0}, {0, 0, 1}}, hole{{m[0], m[1], 0}, {0, 0, 1}};
+            unsigned long long nt = 0, nf = 0;
+            for (long long x = 0; x < m[0]; x++)
+                for (long long y = 0; y < m[1]; y++)
+                    if (in(x, y)) { nt++; bb.lo[0] = std::min(bb.lo[0], x); bb.hi[0] = std::max(bb.hi[0], x + 1); bb.lo[1] = std::min(bb.lo[1], y); bb.hi[1] = std::max(bb.hi[1], y + 1); }
+            for (long long x = bb.lo[0]; x < bb.hi[0]; x++)
+                for (long long y = bb.lo[1]; y < bb.hi[1]; y++)
+                    if (!in(x, y)) { nf++; hole.lo[0] = std::min(hole.lo[0], x); hole.hi[0] = std::max(hole.hi[0], x + 1); hole.lo[1] = std::min(hole.lo[1], y); hole.hi[1] = std::max(hole.hi[1], y + 1); }
+            std::vector<B> out;
+            const bool ok = ykh::ring_strips(bb, nt, hole, nf, out);
+            std::vector<int> cover((size_t)(m[0] * m[1]), 0);
+            bool inside = true, disjoint = true, all = true;
+            for (const B& b : out)
+                for (long long x = b.lo[0]; x < b.hi[0]; x++)
+                    for (long long y = b.lo[1]; y < b.hi[1]; y++) { cover[(size_t)(x * m[1] + y)]++; inside = inside && in(x, y); }
+            for (long long x = 0; x < m[0]; x++)
+                for (long long y = 0; y < m[1]; y++) {
+                    if (cover[(size_t)(x * m[1] + y)] > 1) disjoint = false;
+                    if (in(x, y) && cover[(size_t)(x * m[1] + y)] == 0) all = false;
+                }
+            printf(",\n{\"region\": \"%s\", \"found\": %d, \"boxes\": %zu, \"valid_points\": %llu, \"full\": %d, \"disjoint\": %d, \"covering\": %d, \"queries\": 2, \"profiles\": 0}",
+                   name, (int)ok, out.size(), nt, (int)inside, (int)disjoint, (int)(all || !ok));
+        };
+        // the boundary ring around an interior (swe2d / wave2d: the complement of `x > first + 1 && x < last - 1 && ...`)
+        ring("ring2d", [&](long long x, long long y) { return !(x >= 2 && x < m[0] - 2 && y >= 3 && y < m[1] - 1); });
+        // the interior touches one side of the grid: three strips
+        ring("ring2d_open_side", [&](long long x, long long y) { return !(x >= 0 && x < m[0] - 4 && y >= 3 && y < m[1] - 3); });
+        // not rings: two separate holes; an L-shaped hole; a solid box (no hole at all)
+        ring("two_holes2d", [&](long long x, long long y) { return !((x >= 3 && x < 8 && y >= 3 && y < 8) || (x >= 20 && x < 25 && y >= 20 && y < 25)); });
+        ring("l_hole2d", [&](long long x, long long y) { return !((x >= 5 && x < 30 && y >= 5 && y < 10) || (x >= 5 && x < 10 && y >= 5 && y < 30)); });
+        ring("solid2d", [&](long long x, long long y) { return x >= 4 && y >= 4; });
+    }
     printf("]\n");
     return 0;
 }

@@ -37,3 +37,17 @@ def test_other_regions_are_left_to_the_per_point_predicate(results, region):
     r = results[region]
     assert r["found"] == 0, r               # (the caller then keeps the point kernel with the condition evaluated per point)
     assert r["profiles"] <= 2, r            # ... and finds out quickly
+
+
+@pytest.mark.parametrize("region,boxes", [("ring2d", 4), ("ring2d_open_side", 3)])
+def test_two_d_rings_become_strips(results, region, boxes):
+    """round 6 (`ring_strips`): the complement of an interior condition in a 2-D grid -- swe2d defines 31 of its scratch vars on such a
+    ring -- is a box minus a solid hole: two reductions (the points where the condition holds, the points of their box where it does
+    not) and at most four strips"""
+    r = results[region]
+    assert r["found"] == 1 and r["boxes"] == boxes and r["full"] == 1 and r["disjoint"] == 1 and r["covering"] == 1, r
+
+
+@pytest.mark.parametrize("region", ["two_holes2d", "l_hole2d", "solid2d"])
+def test_two_d_regions_that_are_not_rings_are_refused(results, region):
+    assert results[region]["found"] == 0 and results[region]["boxes"] == 0, results[region]

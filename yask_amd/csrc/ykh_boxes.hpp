@@ -74,4 +74,31 @@ bool decompose_full_boxes(const BoxT& bb0, unsigned long long total, Query&& que
     return covered == total && !out.empty();
 }
 
+// A ring: a box minus a box (2-D solutions; Solution::prepare).  The complement of an interior condition inside a grid is the boundary
+// ring around the interior -- not a solid box, yet two reductions describe it exactly: count + bounding box `bb` of the points where the
+// condition holds, and count + bounding box `hole` of the points of bb where it does NOT.  If the hole is full (n_false == volume(hole))
+// and nothing else is missing (n_true + n_false == volume(bb)), the region is bb \ hole: at most four strips, emitted here.
+// Returns false (no strips) when the region is not such a ring.  Dims 0 and 1; dim 2 of every strip is bb's.
+template <class BoxT>
+bool ring_strips(const BoxT& bb, unsigned long long n_true, const BoxT& hole, unsigned long long n_false, std::vector<BoxT>& out) {
+    auto vol2 = [](const BoxT& b) {
+        unsigned long long v = 1;
+        for (int d = 0; d < 2; d++) v *= (unsigned long long)(b.hi[d] > b.lo[d] ? b.hi[d] - b.lo[d] : 0);
+        return v;
+    };
+    if (n_false == 0 || n_false != vol2(hole) || n_true + n_false != vol2(bb)) return false;
+    for (int d = 0; d < 2; d++)
+        if (hole.lo[d] < bb.lo[d] || hole.hi[d] > bb.hi[d]) return false;
+    auto add = [&](long long l0, long long h0, long long l1, long long h1) {
+        BoxT b = bb;
+        b.lo[0] = l0; b.hi[0] = h0; b.lo[1] = l1; b.hi[1] = h1;
+        if (b.hi[0] > b.lo[0] && b.hi[1] > b.lo[1]) out.push_back(b);
+    };
+    add(bb.lo[0], hole.lo[0], bb.lo[1], bb.hi[1]);          // rows before the hole
+    add(hole.hi[0], bb.hi[0], bb.lo[1], bb.hi[1]);          // rows after it
+    add(hole.lo[0], hole.hi[0], bb.lo[1], hole.lo[1]);      // left of it
+    add(hole.lo[0], hole.hi[0], hole.hi[1], bb.hi[1]);      // right of it
+    return true;
+}
+
 }  // namespace ykh

@@ -425,6 +425,9 @@ public:
     // the part then runs its unpredicated kernels box by box.  Empty: the point kernel evaluates the condition per point.
     std::vector<std::vector<Box>> part_boxes;
     bool in_part_boxes_ = false;                     // launch_part_variant is walking a part's box list
+    // per BOX of a part's list: the kernel shape the timing pass kept for that box (a shell's z-slabs are 20 points thin, its x-slabs
+    // are whole planes: one shape does not fit both); empty = the part's shape for every box.  Used when the part runs on its tuned shape.
+    std::vector<std::vector<int>> part_box_variant;
     bool find_part_boxes(int part, const Box& bb, unsigned long long count, std::vector<Box>& out);
     std::vector<Box> part_hole;            // 2-D: the solid box of points where a ring-shaped condition does not hold (empty: none)
     bool part_needs_predicate(int part) const {      // only the point kernel evaluates the condition per point

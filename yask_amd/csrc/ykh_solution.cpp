@@ -507,6 +507,7 @@ void Solution::prepare() {
     part_bb_solid.assign(impl.parts.size(), 0);
     part_boxes.assign(impl.parts.size(), std::vector<Box>());
     part_hole.assign(impl.parts.size(), Box{{0, 0, 0}, {0, 0, 0}});
+    part_box_variant.assign(impl.parts.size(), std::vector<int>());
     {
         int* dbb = nullptr;
         for (size_t p = 0; p < impl.parts.size(); p++) {
@@ -576,20 +577,9 @@ void Solution::prepare() {
                 std::memcpy(&nhole, &out[6], sizeof(nhole));
                 Box hole = bb;
                 for (int d = 0; d < 2; d++) { hole.lo[d] = out[d]; hole.hi[d] = out[3 + d] + 1; }
-                unsigned long long hvol = 1;
-                for (int d = 0; d < 2; d++) hvol *= (unsigned long long)std::max<idx_t>(0, hole.hi[d] - hole.lo[d]);
-                if (nhole > 0 && nhole == hvol && count + nhole == vol) {
+                std::vector<Box> strips;
+                if (ring_strips(bb, (unsigned long long)count, hole, nhole, strips)) {       // (csrc/ykh_boxes.hpp; tests/test_part_boxes_cpu.py)
                     part_hole[p] = hole;
-                    std::vector<Box> strips;
-                    auto add = [&](idx_t l0, idx_t h0, idx_t l1, idx_t h1) {
-                        Box b = bb;
-                        b.lo[0] = l0; b.hi[0] = h0; b.lo[1] = l1; b.hi[1] = h1;
-                        if (!b.empty()) strips.push_back(b);
-                    };
-                    add(bb.lo[0], hole.lo[0], bb.lo[1], bb.hi[1]);          // rows before the hole
-                    add(hole.hi[0], bb.hi[0], bb.lo[1], bb.hi[1]);          // rows after it
-                    add(hole.lo[0], hole.hi[0], bb.lo[1], hole.lo[1]);      // left of it
-                    add(hole.lo[0], hole.hi[0], hole.hi[1], bb.hi[1]);      // right of it
                     part_boxes[p] = std::move(strips);
                 }
             }
@@ -853,10 +843,13 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
     // a sub-domain part with a list of full boxes: one launch per box that meets the request (every kernel family is legal there)
     if (!in_part_boxes_ && (size_t)part < part_boxes.size() && !part_boxes[part].empty()) {
         ScopedSet<bool> walking(in_part_boxes_, true);
-        for (const Box& fb : part_boxes[part]) {
+        const bool per_box = (size_t)part < part_box_variant.size() && part_box_variant[part].size() == part_boxes[part].size() &&
+                             variant == part_variant[part];
+        for (size_t bi = 0; bi < part_boxes[part].size(); bi++) {
+            const Box& fb = part_boxes[part][bi];
             Box b = box_in;
             for (int d = 0; d < MAX_DOMAIN_DIMS; d++) { b.lo[d] = std::max(b.lo[d], fb.lo[d]); b.hi[d] = std::min(b.hi[d], fb.hi[d]); }
-            if (!b.empty()) launch_part_variant(part, variant, xchunk, t, b, s);
+            if (!b.empty()) launch_part_variant(part, per_box ? part_box_variant[part][bi] : variant, per_box ? 0 : xchunk, t, b, s);
         }
         return;
     }

@@ -440,6 +440,34 @@ void Solution::tune_variants(bool quick, bool fresh_storage) {
         if (best_sp_v >= 0 && best_sp < 0.95 * best) { best_v = best_sp_v; best_xc = best_sp_xc; }
         part_variant[p] = best_v;
         part_xchunk[p] = best_xc;
+        // A part that runs over a LIST of boxes (the shell of an absorbing boundary: thin z-slabs, whole-plane x-slabs; the strips of a
+        // 2-D ring: long rows and 4-point-wide columns): the shape that is fastest over all of them together is not the fastest on each --
+        // one more pass times every clean shape on every box by itself and keeps the winner per box ("per-box shape
+        // choice for shell parts").  One rank only: the boxes of different ranks differ, a collective timing per box would not line up.
+        if ((size_t)p < part_box_variant.size()) part_box_variant[p].clear();
+        if (!many && !pred && (size_t)p < part_boxes.size() && part_boxes[p].size() > 1 && pi.variants.size() > 1) {
+            std::vector<int> choice(part_boxes[p].size(), best_v);
+            ScopedSet<bool> walking(in_part_boxes_, true);              // (launch_part_variant: this IS one box of the list)
+            for (size_t bi = 0; bi < part_boxes[p].size(); bi++) {
+                double bbest = 1e30;
+                for (size_t k = 0; k < pi.variants.size(); k++) {
+                    if (force_scalar && k > 0) break;
+                    if (std::strncmp(pi.variants[k].name, "abl", 3) == 0) continue;
+                    if (!fast_div && std::strstr(pi.variants[k].name, "_fd")) continue;
+                    if (k != (size_t)best_v && variant_scratch_bytes(pi.variants[k]) > 0) continue;       // (spilling shapes: only the part's own choice)
+                    launch_part_variant((int)p, (int)k, 0, 0, part_boxes[p][bi], compute_stream);       // warm-up
+                    YKH_HIP(hipEventRecord(e0, compute_stream));
+                    for (int r = 0; r < 3; r++) launch_part_variant((int)p, (int)k, 0, 0, part_boxes[p][bi], compute_stream);
+                    YKH_HIP(hipEventRecord(e1, compute_stream));
+                    YKH_HIP(hipEventSynchronize(e1));
+                    float ms = 0;
+                    YKH_HIP(hipEventElapsedTime(&ms, e0, e1));
+                    if (env->trace) fprintf(stderr, "auto-tuner: part %s box %zu variant %s: %.4f ms\n", pi.meta->name, bi, pi.variants[k].name, ms / 3);
+                    if (ms < bbest * 0.97) { bbest = ms; choice[bi] = (int)k; }       // (a later shape must win by 3 %: ties keep the earlier)
+                }
+            }
+            part_box_variant[p] = choice;
+        }
     }
     // fused scratch groups (ykh_fused.hpp) against one sweep per part: a whole step each way, the faster is kept
     if (fused_usable() && fuse_scratch_mode < 0) {
@@ -470,6 +498,7 @@ void Solution::tune_variants(bool quick, bool fresh_storage) {
         for (auto& v : vars) if (v->is_allocated() && !v->fixed_size) YKH_HIP(hipMemsetAsync(v->dptr, 0, std::max<size_t>(v->bytes(), 256), compute_stream));
     YKH_HIP(hipStreamSynchronize(compute_stream));
     drop_launch_plans();          // (the kernel shapes may have changed)
+    drop_step_graphs();           // (... per box too, which the graphs' keys do not see)
 }
 
 idx_t Solution::compare_data(const Solution& ref, double eps) const {
