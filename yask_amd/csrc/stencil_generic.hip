@@ -112,6 +112,10 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
         {
             p.variants.push_back(vecpt_variant<P, VZ, 64, 4, 1>());
             p.default_variant = (int)p.variants.size() - 1;
+            // parts with many reads and no other vector family (test_partial_3d: 79 operands, 346 VGPRs with 16-byte lanes = one wave per
+            // SIMD): the same kernel with 8-byte lanes needs half the registers per operand
+            if constexpr (VZ == 4 && P::n_reads > 64 && P::n_writes < 12 && !march_eligible<P>())
+                p.variants.push_back(vecpt_variant<P, 2, 64, 4, 1>());
             if constexpr (march_eligible<P>() && P::n_groups <= 48) {
                 // 8-byte lanes keep the per-thread queue state small (ykh_march.hpp); tile 128 x 8
                 if constexpr (MarchCfg<P, 2, 64, 8>::lds_bytes <= 160 * 1024) {

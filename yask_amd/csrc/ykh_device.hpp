@@ -274,7 +274,14 @@ struct NaiveAcc {
     __device__ __forceinline__ V rd() const {
         const T* p = (const T*)a.ptr[G];
         if constexpr (P::group_full[G]) return (p + ((idx_t)DX * a.sx + (idx_t)DY * a.sy + DZ))[c];
-        else return p[(idx_t)(x + DX) * a.gsx[G] + (idx_t)(y + DY) * a.gsy[G] + (idx_t)(z + DZ) * a.gsz[G]];
+        else {
+            // a var over a subset of the domain dims (its strides are 0 in the dims it lacks): the point's own offset once per GROUP (the
+            // same expression for every read of the group: one evaluation), the read's offset as a uniform term the scalar unit computes.
+            // Written as (x + DX) * gsx + ... every read cost three 64-bit vector multiplies: test_partial_3d, 59 such reads per point,
+            // spent more instructions on addresses than cube spends on its 125 additions (round 6).
+            const idx_t base = (idx_t)x * a.gsx[G] + (idx_t)y * a.gsy[G] + (idx_t)z * a.gsz[G];
+            return p[base + ((idx_t)DX * a.gsx[G] + (idx_t)DY * a.gsy[G] + (idx_t)DZ * a.gsz[G])];
+        }
     }
     template <int G>
     __device__ __forceinline__ void wr(V v) const {

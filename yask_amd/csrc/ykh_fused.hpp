@@ -228,9 +228,13 @@ __global__ void __launch_bounds__(NT) fused2d_kernel(const PartArgs* __restrict_
     extern __shared__ __attribute__((aligned(16))) unsigned char ykh_smem[];
     T* lds = reinterpret_cast<T*>(ykh_smem);
     const int ti0 = g.i0 + (int)(blockIdx.x / (unsigned)g.ntj) * TI, tj0 = g.j0 + (int)(blockIdx.x % (unsigned)g.ntj) * TJ;
-    // (points of a slot that no part of this tile defines -- outside every condition -- read as 0, like a fresh scratch array)
-    for (int k = threadIdx.x; k < C::tab.n_slots * C::SLOT_ELEMS; k += NT) lds[k] = T(0);
-    __syncthreads();
+    // (Points of a slot that no part defines -- outside every condition -- hold whatever the slot held before, as the reference's per-thread
+    //  scratch arrays do (never initialised, stencil_calc.cpp:40-289) and as the device arrays of the part-by-part path do from step to
+    //  step: a solution must not read them.  The first version zero-filled the slots per tile -- 36 LDS stores per thread and a barrier:
+    //  1.94 -> 1.91 ms for swe2d, 0.372 -> 0.359 for wave2d without it, same-box A/B, job r6q.)
+    //  Also measured and NOT kept (jobs r6o / r6p, same box, alternating): a uniform fast path that skips the per-point test on interior
+    //  tiles and a fixed-trip-count form of the point loop -- 21 % fewer vector instructions by the SQ counters and 12 % SLOWER (2.16 ms):
+    //  the extra uniform branches and scalar work cost more issue slots than the v_min3 tests they saved.
     fused_all<TR, C, LEVEL, TI, TJ, NT>(args, g, lds, ti0, tj0, LIST{}, std::make_integer_sequence<int, LIST::N>{});
 }
 

@@ -35,7 +35,9 @@ struct VecPtAcc {
         if constexpr (P::group_full[G])      // uniform base + uniform offset, + c (no per-group strides in SGPRs)
             pz = ((const T*)a.ptr[G] + ((idx_t)DX * a.sx + (idx_t)DY * a.sy + q * VZ)) + c;
         else {
-            const T* p = (const T*)a.ptr[G] + (idx_t)(x + DX) * a.gsx[G] + (idx_t)(y + DY) * a.gsy[G];
+            // (the point's offset once per group, the read's offset as a uniform term: see NaiveAcc::rd)
+            const idx_t base = (idx_t)x * a.gsx[G] + (idx_t)y * a.gsy[G];
+            const T* p = (const T*)a.ptr[G] + base + ((idx_t)DX * a.gsx[G] + (idx_t)DY * a.gsy[G]);
             if (a.gsz[G] == 0) return V(p[0]);                 // var without the unit-stride dim: broadcast
             pz = p + z0 + q * VZ;
         }
