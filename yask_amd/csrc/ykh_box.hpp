@@ -141,6 +141,22 @@ struct BoxCfg {
         return t;
     }
     static constexpr BoxTab tab = make();
+    // the largest y / z reach of the groups that are loaded where they are used (kind 3): the thread's own row offset is clamped ONCE so
+    // that every such read stays inside the allocation, and a read is then that offset + a uniform term (BoxAcc::rd)
+    struct K3 { int yl, yh, zlv, zhv; };
+    static constexpr K3 make_k3() {
+        K3 k = {0, 0, 0, 1};
+        for (int g = 0; g < NG; g++) {
+            if (tab.kind[g] != 3) continue;
+            const BoxShape s = box_shape<P>(g);
+            if (-s.ylo > k.yl) k.yl = -s.ylo;
+            if (s.yhi > k.yh) k.yh = s.yhi;
+            if ((-s.zlo + VZ - 1) / VZ > k.zlv) k.zlv = (-s.zlo + VZ - 1) / VZ;
+            if ((s.zhi + VZ - 1) / VZ + 1 > k.zhv) k.zhv = (s.zhi + VZ - 1) / VZ + 1;       // (+1: the second vector of a shifted pair)
+        }
+        return k;
+    }
+    static constexpr K3 k3 = make_k3();
     static constexpr int RING_TOT = tab.roff[NG], NVTOT = tab.voff[NG], NSTOT = tab.soff[NG];
     static constexpr size_t lds_bytes = sizeof(T) * (size_t)(RING_TOT > 0 ? RING_TOT : 1);
     // reads served from the LDS rings -- or from small tables that lack a dim (kind 4: L1-resident); what is left are the kind-3 reads
@@ -169,6 +185,7 @@ struct BoxAcc {
     const V (&nx)[C::NG];                              // centre-only operands
     int x, y, z0;            // first row, first of the VZ points
     V (&out)[MAX_GROUPS];
+    const unsigned (&o3)[C::RY];                       // byte offset of the thread's rows within a plane, clamped for the kind-3 reads
     template <class F>
     __device__ __forceinline__ static V rows(F f) {   // f(row) -> V1
         if constexpr (RY == 1) return f(std::integral_constant<int, 0>{});
@@ -190,15 +207,20 @@ struct BoxAcc {
         constexpr int e = DZ - qq * VZ;
         if constexpr (C::tab.kind[G] == 1) return nx[G];
         else if constexpr (C::tab.kind[G] == 3) {
-            // a group whose ring did not fit: aligned global loads where the value is used, clamped into the allocation (threads of
-            // a ragged tile's overhang compute on whatever lies there and store nothing)
-            const T* px = (const T*)a.ptr[G] + (idx_t)clampi(x + DX, a.ax0, a.ax1 - 1) * a.sx;
-            const int zl = clampi(z0 + qq * VZ, a.az0, a.az1 - VZ), zh = clampi(z0 + (qq + 1) * VZ, a.az0, a.az1 - VZ);
+            // a group whose ring did not fit: aligned global loads where the value is used.  The address is (uniform plane base, in
+            // SGPRs) + (the thread's row offset, clamped once for all such reads: o3) + (a uniform term for this read's dy / dz) -- the
+            // saddr form of global_load with one 32-bit add.  (Until round 6 every such read clamped y and z itself and multiplied by
+            // the run-time row pitch in 64 bits: tti, 40 of these per point.)  Threads of a ragged tile's overhang compute on whatever
+            // lies at the clamped rows and store nothing.
+            const idx_t org = (idx_t)a.ay0 * a.sy + a.az0;
+            // (no sbase() here: its opaque SGPR pair per call -- 40 of them in tti -- spilled the scalar file into vector registers)
+            const T* pb = (const T*)a.ptr[G] + (org + (idx_t)clampi(x + DX, a.ax0, a.ax1 - 1) * a.sx);
+            const int d = (DY * (int)a.sy + qq * VZ) * (int)sizeof(T);                               // uniform
             return rows([&](auto jc) -> V1 {
                 constexpr int j = decltype(jc)::value;
-                const T* p = px + (idx_t)clampi(y + j + DY, a.ay0, a.ay1 - 1) * a.sy;
-                if constexpr (e == 0) return ldv<V1>(p + zl);
-                else return zshiftn<T, VZ, e>(ldv<V1>(p + zl), ldv<V1>(p + zh));
+                const unsigned o = o3[j] + (unsigned)d;
+                if constexpr (e == 0) return ldv_b<V1>(pb, o);
+                else return zshiftn<T, VZ, e>(ldv_b<V1>(pb, o), ldv_b<V1>(pb, o + (unsigned)(VZ * sizeof(T))));
             });
         } else if constexpr (C::tab.kind[G] == 4) {
             // a var over a subset of the domain dims (its strides are 0 in the dims it lacks), read at an offset: every var shares the
@@ -279,6 +301,13 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) box_kernel(const PartArgs a) {
     };
     unsigned ooff[RY];
     static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; ooff[j] = plane_off(yc[j], zc); });
+    // the same for the kind-3 reads: clamped so that row + dy and vector + dz stay inside the allocation for every such read (points of
+    // the launch's box are never moved by it: their reads lie in the halos, which are allocated)
+    unsigned o3[RY];
+    static_for<RY>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        o3[j] = plane_off(clampi(myy0 + j, a.ay0 + C::k3.yl, a.ay1 - 1 - C::k3.yh), clampi(myz, a.az0 + C::k3.zlv * VZ, a.az1 - VZ - C::k3.zhv * VZ));
+    });
 
     // which vectors of a group's slab this thread brings in: vector h = tid + k * NT of the (rows x vectors) slab
     unsigned vofs[C::NVTOT > 0 ? C::NVTOT : 1];       // byte offset within the plane
@@ -390,7 +419,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) box_kernel(const PartArgs a) {
         static_for<NG>([&](auto gc) { constexpr int g = decltype(gc)::value; if constexpr (C::tab.kind[g] == 1) cur[g] = nxt[g]; });
         if (x + 1 < xe) fetch_once(x + 1);
         {
-            BoxAcc<C, P> acc{a, ring, sl, tofs, cur, x, myy0, myz, out};
+            BoxAcc<C, P> acc{a, ring, sl, tofs, cur, x, myy0, myz, out, o3};
             P::eval(acc);
         }
         static_for<RY>([&](auto jc) {
