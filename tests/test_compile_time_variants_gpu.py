@@ -124,3 +124,75 @@ def test_permuted_star_runs_the_linear_star_kernel_at_size(gpu):
     # radius 3: halos of 3 in every domain dim, by NAME
     assert [p.get_left_halo_size(d) for d in ("x", "y", "z")] == [3, 3, 3]
     s.end_solution()
+
+
+# ------------------------------------------------------------------ a permuted solution cut over ranks
+def _rank_worker(rank, world, port, name, nr, q):
+    import os
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      YASK_HIP_TRANSPORT="ipc", YASK_HIP_WAIT_TIMEOUT_S="30", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from yask_amd import yk_factory
+    meta = INDEX[name]
+    fac = yk_factory(meta["stencil"])
+    env = fac.new_env()
+    env.init_from_launcher()
+    s = fac.new_solution(env)
+    s.set_overall_domain_size_vec(meta["size"])
+    s.set_num_ranks_vec(list(nr))
+    s.prepare_solution()
+    for i, v in enumerate(s.get_vars()):
+        v.set_elements_hash(*meta["init"], hash_id=i)
+    s.run_solution(0, meta["steps"] - 1)
+    dom = s.get_domain_dim_names()
+    f = dict(zip(dom, s.get_first_rank_domain_index_vec()))
+    l = dict(zip(dom, s.get_last_rank_domain_index_vec()))
+    out = {}
+    for key in meta["arrays"]:
+        vname, t = key.split("@")
+        var = s.get_var(vname)
+        dn = var.get_dim_names()
+        if len(dn) != len(dom) + 1 or dn[0] != s.get_step_dim_name() or int(t) != meta["steps"]:
+            continue
+        first = [int(t)] + [f[d] for d in dn[1:]]
+        last = [int(t)] + [l[d] for d in dn[1:]]
+        out[key] = (first[1:], last[1:], np.asarray(var.get_elements_in_slice(first, last))[0])
+    q.put((rank, out))
+    env.global_barrier()
+    s.end_solution()
+
+
+@pytest.mark.parametrize("tag,nr", [("iso3dfd-r3zxy", (2, 1, 1)), ("iso3dfd-r3zxy", (1, 1, 2)), ("test_3d-zyx", (1, 2, 1)), ("test_stages_3d-xzy", (2, 1, 2))],
+                         ids=["iso3dfd-r3zxy-2x1x1", "iso3dfd-r3zxy-1x1x2", "test_3d-zyx-1x2x1", "test_stages_3d-xzy-2x1x2"])
+def test_permuted_solution_cut_over_ranks_matches_the_reference(gpu, tag, nr):
+    """the rank grid is given in the SOLUTION's domain-dim order (-domain-dims z,x,y: the first entry cuts z); every rank's box of the
+    written var, addressed in the var's declared dim order, equals the reference's one-rank result built with the same flags"""
+    import multiprocessing as mp
+    import socket
+    name = [n for n in CASES if INDEX[n]["stencil"] == tag][0]
+    meta = INDEX[name]
+    z = np.load(G / f"{name}.npz")
+    world = int(np.prod(nr))
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, name, nr, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    parts = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    checked = 0
+    for key in meta["arrays"]:
+        if not all(key in out for _, out in parts):
+            continue
+        ref = z[key].astype(np.float64)
+        got = np.full(ref.shape, np.nan)
+        for _, out in parts:
+            first, last, a = out[key]
+            got[tuple(slice(f0, l0 + 1) for f0, l0 in zip(first, last))] = a
+        assert np.isfinite(got).all(), key
+        err = np.abs(got - ref).max() / max(1e-30, np.abs(ref).max())
+        assert err <= 2e-5, (key, err)
+        checked += 1
+    assert checked >= 1
