@@ -104,6 +104,16 @@ GENERIC_CASES = [
     ("test_stages_2d_40x520_s2", "test_stages_2d", (40, 520), 2),
     ("test_misc_2d_40x520_s2", "test_misc_2d", (40, 520), 2),
     ("test_stream_2d_40x520_s2", "test_stream_2d", (40, 520), 2),
+    # round 6: the 1-D solutions on a grid of several tiles of the lifted vector point kernel (1024 points per workgroup): 2300 points, ragged
+    ("test_1d_2300_s2", "test_1d", (2300,), 2),
+    ("test_boundary_1d_2300_s2", "test_boundary_1d", (2300,), 2),
+    ("test_scratch_1d_2300_s2", "test_scratch_1d", (2300,), 2),
+    ("test_scratch_boundary_1d_2300_s3", "test_scratch_boundary_1d", (2300,), 3),
+    ("test_scratch_stages_1d_2300_s2", "test_scratch_stages_1d", (2300,), 2),
+    ("test_stages_1d_2300_s2", "test_stages_1d", (2300,), 2),
+    ("test_stream_1d_2300_s2", "test_stream_1d", (2300,), 2),
+    ("test_func_1d_2300_s2", "test_func_1d", (2300,), 2),
+    ("test_step_cond_1d_2300_s4", "test_step_cond_1d", (2300,), 4),
     # four domain dims (TestStencils.cpp:254-273): the outermost one is a loop of launches on the GPU
     ("test_4d_8x10x12x14_s2", "test_4d", (8, 10, 12, 14), 2),
     # reverse-time stencil A(t-1) = f(A(t)) (TestStencils.cpp:510-518), driven as run_solution(0, -2): steps descend

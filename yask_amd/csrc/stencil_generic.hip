@@ -181,6 +181,14 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
         // launch sweeps the inner three -- with the vector point kernel too since round 6 (was: scalar point kernel only)
         p.variants.push_back(vecpt_variant<P, VZ, 64, 4, 1>());
         p.default_variant = (int)p.variants.size() - 1;
+    } else if (ndd == 1) {
+        // one domain dim: the vector point kernel on the part lifted to one row of one plane (ykh_lift2d.hpp, SHIFT = 2)
+        if constexpr (lift2d_shape<P, 2>()) {
+            KernelVariant kv = vecpt_variant<Lift2D<P, 2>, VZ, 256, 1, 1>();
+            kv.lift1d = true;
+            p.variants.push_back(kv);
+            p.default_variant = (int)p.variants.size() - 1;
+        }
     } else if (ndd == 2) {
         // two domain dims: the 3-D families on the part lifted to one x plane (ykh_lift2d.hpp) -- 16-byte vectors along the unit-stride
         // dim instead of the scalar point kernel's 4-byte loads (wave2d, swe2d: 15 / 65 full-domain sweeps per step); parts with many

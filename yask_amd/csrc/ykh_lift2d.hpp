@@ -18,51 +18,58 @@
 
 namespace ykh {
 
-template <class A>
+// SHIFT = 1: two domain dims (d0, d1) -> (y, z); SHIFT = 2: one domain dim d0 -> z (round 6: the reference's 1-D test solutions ran the
+// scalar point kernel at 0.10-0.39 of 8 TB/s)
+template <class A, int SHIFT = 1>
 struct Lift2DAcc {
     typedef typename A::V V;
     A& a;
     template <int G, int D0, int D1, int DZ>
-    __device__ __forceinline__ V rd() const { static_assert(DZ == 0, "a 2-D part has no third offset"); return a.template rd<G, 0, D0, D1>(); }
+    __device__ __forceinline__ V rd() const {
+        static_assert(DZ == 0 && (SHIFT == 1 || D1 == 0), "the part has an offset in a dim it is lifted out of");
+        if constexpr (SHIFT == 1) return a.template rd<G, 0, D0, D1>();
+        else return a.template rd<G, 0, 0, D0>();
+    }
     template <int G>
     __device__ __forceinline__ void wr(V v) { a.template wr<G>(v); }
     __device__ __forceinline__ void pin(V& v) const { a.pin(v); }
     template <class L, class R> __device__ __forceinline__ V sub(L l, R r) const { return a.sub(l, r); }
     template <class L, class R> __device__ __forceinline__ V div(L l, R r) const { return a.div(l, r); }
-    template <int D> __device__ __forceinline__ V idx() const { return a.template idx<D + 1>(); }
+    template <int D> __device__ __forceinline__ V idx() const { return a.template idx<D + SHIFT>(); }
     __device__ __forceinline__ V step() const { return a.step(); }
 };
 
 template <class P>
 struct Lift2DTab { ReadOff reads[P::n_reads > 0 ? P::n_reads : 1]; };
-template <class P>
+template <class P, int SHIFT>
 constexpr Lift2DTab<P> make_lift2d_tab() {
     Lift2DTab<P> t = {};
-    for (int i = 0; i < P::n_reads; i++) t.reads[i] = ReadOff{P::reads[i].g, 0, P::reads[i].dx, P::reads[i].dy};
+    for (int i = 0; i < P::n_reads; i++)
+        t.reads[i] = SHIFT == 1 ? ReadOff{P::reads[i].g, 0, P::reads[i].dx, P::reads[i].dy} : ReadOff{P::reads[i].g, 0, 0, P::reads[i].dx};
     return t;
 }
 // a part whose reads have no offset in a third dim (necessary for a 2-D part; the registry also checks the solution's dim count)
-template <class P>
+template <class P, int SHIFT = 1>
 constexpr bool lift2d_shape() {
     for (int i = 0; i < P::n_reads; i++)
-        if (P::reads[i].dz != 0) return false;
+        if (P::reads[i].dz != 0 || (SHIFT == 2 && P::reads[i].dy != 0)) return false;
     return true;
 }
 
-template <class P>
+template <class P, int SHIFT = 1>
 struct Lift2D {
     typedef typename P::real_t real_t;
     static constexpr int n_groups = P::n_groups;
     static constexpr const AccessGroup (&groups)[P::n_groups] = P::groups;
     static constexpr const bool (&group_full)[P::n_groups] = P::group_full;
-    static constexpr Lift2DTab<P> tab = make_lift2d_tab<P>();
+    static constexpr Lift2DTab<P> tab = make_lift2d_tab<P, SHIFT>();
     static constexpr int n_reads = P::n_reads;
     static constexpr const ReadOff (&reads)[P::n_reads > 0 ? P::n_reads : 1] = tab.reads;
     static constexpr int n_writes = P::n_writes;
     static constexpr const int (&writes)[P::n_writes] = P::writes;
     template <class A>
     __device__ __forceinline__ static void eval(A& a) {
-        Lift2DAcc<A> l{a};
+        Lift2DAcc<A, SHIFT> l{a};
         P::eval(l);
     }
     static constexpr bool has_lin = false;

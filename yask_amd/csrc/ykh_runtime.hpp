@@ -61,6 +61,7 @@ struct KernelVariant {
     // a 3-D kernel family instantiated on Lift2D<part> (ykh_lift2d.hpp): the part has two domain dims (d0, d1), the kernel sees them
     // as (y, z) of one x plane; Solution::launch_part_variant() moves the box and the PartArgs up one dim before the launch
     bool lift2d = false;
+    bool lift1d = false;          // ... one domain dim d0, seen as z of one row of one plane
 };
 // bytes of scratch (private segment) per thread of a variant's kernel(s) -- the maximum over the kernels of a cluster variant;
 // > 0 means hipcc spilled registers

@@ -565,7 +565,7 @@ void Solution::prepare() {
             // itself solid, the valid points are at most four strips: the part runs its unpredicated kernels strip by strip, and the
             // fused scratch kernel tests two boxes instead of evaluating a 64-bit predicate per point.
             part_hole[p] = Box{{0, 0, 0}, {0, 0, 0}};
-            if (!part_bb_solid[p] && count > 0 && ndd == 2 && !has_outer && !wf_multi()) {
+            if (!part_bb_solid[p] && count > 0 && ndd <= 2 && !has_outer && !wf_multi()) {      // (one domain dim: the hole leaves two intervals)
                 YKH_HIP(hipMemcpyAsync(dbb, init, sizeof(init), hipMemcpyHostToDevice, compute_stream));
                 fill_part_args((int)p, 0, bb, a);
                 a.nxc = -1;
@@ -880,6 +880,18 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
         a.lane_dim = 2;
         box.lo[2] = box.lo[1]; box.hi[2] = box.hi[1]; box.lo[1] = box.lo[0]; box.hi[1] = box.hi[0]; box.lo[0] = 0; box.hi[0] = 1;
     }
+    if (kv.lift1d) {
+        // a 1-D part on a 3-D kernel family: d0 -> z of ONE row of ONE plane (everything indexed by domain dim moves up two places)
+        for (int g = 0; g < impl.parts[part].meta->n_groups; g++) { a.gsz[g] = (int)a.gsx[g]; a.gsy[g] = 0; a.gsx[g] = 0; }
+        a.sy = 0; a.sx = 0;
+        a.z0 = a.x0; a.z1 = a.x1; a.y0 = 0; a.y1 = 1; a.x0 = 0; a.x1 = 1;
+        a.az0 = a.ax0; a.az1 = a.ax1; a.ay0 = 0; a.ay1 = 1; a.ax0 = 0; a.ax1 = 1;
+        a.ofs_z = a.ofs_x; a.ofs_y = 0; a.ofs_x = 0;
+        a.glast_z = a.glast_x; a.glast_y = 0; a.glast_x = 0;
+        a.dom_z1 = a.dom_x1; a.dom_y1 = 1; a.dom_x1 = 1;
+        a.lane_dim = 2;
+        box.lo[2] = box.lo[0]; box.hi[2] = box.hi[0]; box.lo[1] = 0; box.hi[1] = 1; box.lo[0] = 0; box.hi[0] = 1;
+    }
     if (kv.star) {
         const int vz = kv.vz > 0 ? kv.vz : 16 / elem_bytes();
         idx_t zt0 = box.lo[2] & ~(idx_t)(vz - 1);
@@ -933,6 +945,7 @@ void Solution::launch_part_variant(int part, int variant, idx_t xchunk, idx_t t,
                     if (kv.lift2d) {          // (the callee lifts again: hand it the sub-box in the solution's own two dims)
                         sub.lo[0] = sub.lo[1]; sub.hi[0] = sub.hi[1]; sub.lo[1] = sub.lo[2]; sub.hi[1] = sub.hi[2]; sub.lo[2] = 0; sub.hi[2] = 1;
                     }
+                    if (kv.lift1d) { sub.lo[0] = sub.lo[2]; sub.hi[0] = sub.hi[2]; sub.lo[1] = 0; sub.hi[1] = 1; sub.lo[2] = 0; sub.hi[2] = 1; }
                     launch_part_variant(part, variant, xc, t, sub, s);
                 }
                 return;
