@@ -50,7 +50,7 @@ def _worker(rank, world, port, name, nr, q):
         vname, t = key.split("@")
         var = s.get_var(vname)
         dn = var.get_dim_names()
-        if len(dn) != 3 or dn[0] != s.get_step_dim_name():
+        if len(dn) != len(meta["size"]) + 1 or dn[0] != s.get_step_dim_name():
             continue                                     # (coefficient scalars: inputs)
         out[key] = np.asarray(var.get_elements_in_slice([int(t)] + f, [int(t)] + l))[0]
     q.put((rank, f, l, out, [s.get_kernel_variant(p) for p in range(s.get_num_parts())]))
@@ -58,11 +58,15 @@ def _worker(rank, world, port, name, nr, q):
     s.end_solution()
 
 
-@pytest.mark.parametrize("world,nr", [(2, (2, 1)), (2, (1, 2)), (4, (2, 2))], ids=["2x1", "1x2", "2x2"])
-@pytest.mark.parametrize("stencil", ["wave2d", "swe2d", "test_boundary_2d", "test_scratch_2d"])
+@pytest.mark.parametrize("stencil,world,nr", [(st, w, nr) for st in ("wave2d", "swe2d", "test_boundary_2d", "test_scratch_2d")
+                                              for w, nr in ((2, (2, 1)), (2, (1, 2)), (4, (2, 2)))] +
+                         [(st, w, (w,)) for st in ("test_1d", "test_boundary_1d", "test_scratch_boundary_1d") for w in (2, 4)],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
 def test_two_d_solution_over_ranks_matches_the_reference(gpu, stencil, world, nr):
+    """(and, since the lifted vector kernels serve them too, three of the 1-D solutions over 2 and 4 ranks on their 2300-point goldens)"""
     import multiprocessing as mp
-    name = [n for n in INDEX if INDEX[n].get("generic") and INDEX[n]["stencil"] == stencil and INDEX[n]["size"] == [40, 520]][0]
+    want = [40, 520] if len(nr) == 2 else [2300]
+    name = [n for n in INDEX if INDEX[n].get("generic") and INDEX[n]["stencil"] == stencil and INDEX[n]["size"] == want][0]
     meta = INDEX[name]
     z = np.load(G / f"{name}.npz")
     ctx = mp.get_context("spawn")
@@ -78,13 +82,13 @@ def test_two_d_solution_over_ranks_matches_the_reference(gpu, stencil, world, nr
     checked = 0
     for key in meta["arrays"]:
         ref = z[key].astype(np.float64)
-        if ref.ndim != 2:
+        if ref.ndim != len(nr):
             continue
         got = np.full(ref.shape, np.nan)
         have = False
         for _, f, l, out, _ in parts:
             if key in out:
-                got[f[0]:l[0] + 1, f[1]:l[1] + 1] = out[key]
+                got[tuple(slice(f0, l0 + 1) for f0, l0 in zip(f, l))] = out[key]
                 have = True
         if not have:
             continue
