@@ -26,10 +26,13 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, name, nr, q):
+def _worker(rank, world, port, name, nr, q, fuse=None):
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       YASK_HIP_TRANSPORT="ipc", YASK_HIP_WAIT_TIMEOUT_S="30", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    os.environ.pop("YASK_HIP_FUSE_SCRATCH", None)
+    if fuse is None:
+        os.environ.pop("YASK_HIP_FUSE_SCRATCH", None)
+    else:
+        os.environ["YASK_HIP_FUSE_SCRATCH"] = str(fuse)
     from yask_amd import yk_factory
     meta = INDEX[name]
     fac = yk_factory(meta["stencil"])
@@ -39,7 +42,8 @@ def _worker(rank, world, port, name, nr, q):
     s.set_overall_domain_size_vec(meta["size"])
     s.set_num_ranks_vec(list(nr))
     s.prepare_solution()
-    assert s.get_fused_groups() == [], "a decomposed rank evaluates exterior and interior boxes part by part"
+    if fuse is not None:
+        assert len(s.get_fused_groups()) == (1 if fuse else 0), (fuse, s.get_fused_groups())
     for i, v in enumerate(s.get_vars()):
         off, sc = meta.get("init_vars", {}).get(v.get_name(), meta["init"])
         v.set_elements_hash(off, sc, hash_id=i)
@@ -63,6 +67,18 @@ def _worker(rank, world, port, name, nr, q):
                          [(st, w, (w,)) for st in ("test_1d", "test_boundary_1d", "test_scratch_boundary_1d") for w in (2, 4)],
                          ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
 def test_two_d_solution_over_ranks_matches_the_reference(gpu, stencil, world, nr):
+    _ranks_vs_fixture(stencil, world, nr, None)
+
+
+@pytest.mark.parametrize("fuse", [1, 0], ids=["fused", "part_by_part"])
+@pytest.mark.parametrize("stencil,world,nr", [("wave2d", 2, (1, 2)), ("swe2d", 4, (2, 2)), ("test_scratch_2d", 2, (2, 1))], ids=["wave2d-1x2", "swe2d-2x2", "test_scratch_2d-2x1"])
+def test_fused_scratch_groups_on_decomposed_ranks(gpu, stencil, world, nr, fuse):
+    """a decomposed rank runs a fused group over its whole box and exchanges afterwards (the scratch vars never travel: every rank computes
+    them on its box grown by their halos): forced on and forced off, both against the reference's one-rank result"""
+    _ranks_vs_fixture(stencil, world, nr, fuse)
+
+
+def _ranks_vs_fixture(stencil, world, nr, fuse):
     """(and, since the lifted vector kernels serve them too, three of the 1-D solutions over 2 and 4 ranks on their 2300-point goldens)"""
     import multiprocessing as mp
     want = [40, 520] if len(nr) == 2 else [2300]
@@ -72,7 +88,7 @@ def test_two_d_solution_over_ranks_matches_the_reference(gpu, stencil, world, nr
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, nr, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, nr, q, fuse)) for r in range(world)]
     for p in procs:
         p.start()
     parts = [q.get(timeout=240) for _ in procs]

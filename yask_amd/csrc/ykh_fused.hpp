@@ -17,7 +17,8 @@
 //   * sub-domain conditions are evaluated per point (P::cond), as the scalar point kernel does.
 // Redundant work: the halo ring of a tile is computed by its neighbours too ((TI + h)(TJ + h) / (TI TJ), ~1.5x at h = 4) -- flops
 // and LDS reads instead of 2 HBM sweeps per scratch var.
-// 2-D solutions only (a 3-D tile with halos of 4 does not leave room for 40 scratch vars); one rank; parts without step conditions.
+// 2-D solutions only (a 3-D tile with halos of 4 does not leave room for 40 scratch vars).  A decomposed rank runs the group over its
+// whole box and exchanges afterwards (Solution::run).
 #pragma once
 #include "ykh_device.hpp"
 

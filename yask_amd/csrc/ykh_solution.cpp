@@ -1144,7 +1144,7 @@ void Solution::run(idx_t first_step, idx_t last_step) {
         }
         t += dir * g;
     }
-    if (fused_on && !multi) ensure_fused_args();          // (device tables of the fused scratch groups: never built inside a capture)
+    if (fused_on) ensure_fused_args();                    // (device tables of the fused scratch groups: never built inside a capture)
     // Launch-bound runs: the launches of a whole number of slot periods are captured once and replayed (step graphs, below).
     idx_t t_plain = first_plain;
     if (!wavefront && !multi && !step_timers && step_graph_wanted()) {
@@ -1174,12 +1174,23 @@ void Solution::run(idx_t first_step, idx_t last_step) {
     halves_in_flight_ = false;
     for (idx_t t = t_plain; !wavefront && (dir > 0 ? t <= last_step : t >= last_step); t += dir) {
         for (int st = 0; st < meta->n_stages; st++) {
-            if (fused_on && !multi) {
+            if (fused_on) {
                 const FusedGroupImpl* fg = fused_group_at(st);
                 if (fg && fused_ok_at(*fg, t)) {
-                    // a run of scratch stages and the stage they feed: ONE launch, scratch vars in the LDS (ykh_fused.hpp)
+                    // a run of scratch stages and the stage they feed: ONE launch, scratch vars in the LDS (ykh_fused.hpp).  A decomposed
+                    // rank runs it over its whole box and exchanges afterwards (the scratch vars themselves never travel: every rank
+                    // computes them on its box grown by their halos, from inputs whose halos the previous exchange filled)
+                    cur_phase = multi ? phase_next() : nullptr;
+                    phase_mark(PH_EXT1, compute_stream);
                     launch_fused(*fg, t, compute_stream);
                     note_stage_written(meta->stages[fg->last_stage], t);
+                    if (multi) {
+                        exchange_halos(t, fg->last_stage, /*start_only=*/true, false);
+                        phase_mark(PH_INT1, compute_stream);
+                        exchange_halos(t, fg->last_stage, false, /*finish_only=*/true);
+                        phase_mark(PH_WAIT1, compute_stream);
+                    }
+                    cur_phase = nullptr;
                     st = fg->last_stage;
                     continue;
                 }

@@ -199,10 +199,11 @@ void Solution::issue_step(idx_t t) {
 }
 
 // ------------------------------------------------------------------ fused scratch groups (ykh_fused.hpp)
-// Legal on this solution?  Two domain dims, one rank (a decomposed rank evaluates exterior and interior boxes part by part), no 4th
-// dim, no part whose arithmetic sees the value of the step index (the PartArgs of a group are built once per step-slot phase).
+// Legal on this solution?  Two domain dims, no 4th dim, no wave-front tiling.
 bool Solution::fused_usable() const {
-    if (impl.fused.empty() || ndd != 2 || has_outer || env->nranks > 1 || force_scalar || !variant_override.empty()) return false;
+    // (a decomposed rank may use it too since the end of round 6: the group runs over the whole rank box, then the exchange -- no
+    //  exterior / interior split; wave-front tiling, whose phases run on shrinking boxes, keeps the part-by-part path)
+    if (impl.fused.empty() || ndd != 2 || has_outer || force_scalar || !variant_override.empty() || std::max<idx_t>(mega_block_size[0], block_size[0]) > 1) return false;
     for (auto* list : {&vars, &scratch_vars})          // (the kernel addresses global memory with 32-bit element offsets)
         for (auto& v : *list)
             if ((double)v->slot_elems * (double)std::max(1, v->nslots) >= 2147483648.0) return false;
