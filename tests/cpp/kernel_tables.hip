@@ -60,9 +60,22 @@ void fuse_group(int first, int last, bool first_group) {
     int nsv = 0, max_level = 0;
     for (int v = 0; v < GenTraits::n_vars && v < FUSED_MAX_VARS; v++) nsv += C16::tab.first[v] >= 0;
     for (int i = 0; i < LIST::N; i++) if (LEVEL[i] > max_level) max_level = LEVEL[i];
-    printf("%s{\"fuse_group\": [%d, %d], \"parts\": %d, \"levels\": %d, \"scratch_vars\": %d, \"slots\": %d, \"parts_ok\": %d, \"halo\": [%d, %d, %d, %d], "
+    // the plan's invariant: two scratch vars share a slot only if one's last use lies at an EARLIER level than the other's first write
+    int conflicts = 0, unassigned = 0;
+    for (int v = 0; v < GenTraits::n_vars && v < FUSED_MAX_VARS; v++) {
+        if (C16::tab.first[v] < 0) continue;
+        if (C16::tab.slot[v] < 0 || C16::tab.slot[v] >= C16::tab.n_slots) unassigned++;
+        for (int w = v + 1; w < GenTraits::n_vars && w < FUSED_MAX_VARS; w++) {
+            if (C16::tab.first[w] < 0 || C16::tab.slot[w] != C16::tab.slot[v]) continue;
+            const bool disjoint = C16::tab.last[v] < C16::tab.first[w] || C16::tab.last[w] < C16::tab.first[v];
+            if (!disjoint) conflicts++;
+        }
+    }
+    printf("%s{\"slot_conflicts\": %d, \"unassigned\": %d, ", first_group ? "" : ",\n", conflicts, unassigned);
+    first_group = true;
+    printf("%s\"fuse_group\": [%d, %d], \"parts\": %d, \"levels\": %d, \"scratch_vars\": %d, \"slots\": %d, \"parts_ok\": %d, \"halo\": [%d, %d, %d, %d], "
            "\"lds_16x64\": %zu, \"ok_16x64\": %d, \"lds_8x64\": %zu, \"ok_8x64\": %d}",
-           first_group ? "" : ",\n", first, last, LIST::N, max_level + 1, nsv, C16::tab.n_slots, (int)C16::tab.ok, C16::tab.hl0, C16::tab.hr0, C16::tab.hl1, C16::tab.hr1,
+           "", first, last, LIST::N, max_level + 1, nsv, C16::tab.n_slots, (int)C16::tab.ok, C16::tab.hl0, C16::tab.hr0, C16::tab.hl1, C16::tab.hr1,
            C16::lds_bytes, (int)C16::ok, C8::lds_bytes, (int)C8::ok);
 }
 int main(int argc, char** argv) {

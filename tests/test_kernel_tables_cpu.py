@@ -106,3 +106,8 @@ def test_fused_scratch_group_plans(tmp_path):
     t3 = fused_tables(tmp_path, "test_scratch_3d")
     assert len(t3) == 1 and t3[0]["parts_ok"] == 0 and t3[0]["ok_16x64"] == 0
     assert fused_tables(tmp_path, "iso3dfd") == []
+    # the invariant of the slot assignment, checked on every group the headers list: vars share a slot only when one's last use lies at
+    # an earlier level than the other's first write (a barrier separates levels), and every scratch var of a group has a slot
+    for soln in ("wave2d", "swe2d", "test_scratch_2d", "test_scratch_1d", "test_scratch_stages_1d", "test_scratch_boundary_1d"):
+        for g in fused_tables(tmp_path, soln):
+            assert g["slot_conflicts"] == 0 and g["unassigned"] == 0, (soln, g)
