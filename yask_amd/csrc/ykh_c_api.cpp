@@ -442,9 +442,13 @@ int yk_solution_get_fused_groups(yk_soln_h s, int g, long long* info) {
     Solution& so = S(s);
     if (!so.prepared) YKH_THROW("get_fused_groups() called without calling prepare_solution() first");
     if (!so.fused_on) return 0;
-    const int n = (int)so.impl.fused.size();
+    // (impl.fused lists every tile shape of every group: a group is reported once, on the shape in use)
+    std::vector<const FusedGroupImpl*> used;
+    for (auto& f : so.impl.fused)
+        if (so.fused_group_at(f.first_stage) == &f) used.push_back(&f);
+    const int n = (int)used.size();
     if (info && g >= 0 && g < n) {
-        const FusedGroupImpl& fg = so.impl.fused[g];
+        const FusedGroupImpl& fg = *used[(size_t)g];
         info[0] = fg.n_parts; info[1] = fg.n_scratch_vars; info[2] = fg.n_slots; info[3] = (long long)fg.lds_bytes; info[4] = fg.ti; info[5] = fg.tj;
     }
     return n;

@@ -555,7 +555,8 @@ public:
     void ensure_fused_args();
     void drop_fused_args();
     void launch_fused(const FusedGroupImpl& fg, idx_t t, hipStream_t s);
-    std::vector<std::vector<PartArgs*>> fused_args_;      // [group][phase]
+    std::map<int, int> fused_pick_;                       // first stage of a group -> index into impl.fused of the tile shape in use
+    std::vector<std::vector<PartArgs*>> fused_args_;      // [entry of impl.fused][phase]
     std::string fused_args_key_;
     bool launching_interior = false;      // set by launch_interior() of an overlapped exchange
     bool launching_exterior = false;      // set by run() around the exterior slabs of a decomposed run (thin-slab kernel choice)

@@ -683,6 +683,7 @@ void Solution::prepare() {
     // scratch stages + their consumer as one kernel (ykh_fused.hpp): on where legal unless switched off; the timing pass below
     // (tune_variants) runs a step both ways and keeps the faster when the choice was left open
     fused_on = fused_usable() && fuse_scratch_mode != 0;
+    fused_pick_.clear();
     if (placed && placement_trials > 1) tune_placement();
     else { placement_ms.clear(); placement_chosen = 0; }
     if (env->nranks > 1) small_grid = env->max_over_ranks(small_grid ? 1 : 0) != 0;     // (local sizes may differ by rank)

@@ -289,29 +289,35 @@ void launch_fused2d(const PartArgs* dev_args, const FusedGeom& g, unsigned grid,
     }
     hipLaunchKernelGGL((fused2d_kernel<TR, LIST, LEVEL, TI, TJ, NT>), dim3(grid), dim3(NT), C::lds_bytes, s, dev_args, g);
 }
-// registers the group when every part can be fused and the slots fit the LDS at this tile; else tries the smaller tile
+// registers the group at every tile shape of the candidate list whose slots fit the LDS (largest first: the static default).  Which one is
+// fastest depends on the group: a large tile recomputes less of its halo ring (swe2d, halos of 5 + 4: 1.46x the points at 32 x 64, 2.0x
+// at 32 x 32), a small one lets TWO workgroups share a CU's LDS so that one computes while the other waits at a level's barrier
+// (swe2d: 143 KB of slots at 32 x 64, 81 KB at 32 x 32: 1.91 -> 1.72 ms; wave2d, 6 slots, is the other way round: 0.36 vs 0.48 ms;
+// same-box A/B, job r6w).  prepare_solution() times them (Solution::tune_variants).
+template <class TR, class LIST, const int* LEVEL, int TI, int TJ, int NT>
+void add_fused_cfg(SolnImpl& s, int first_stage, int last_stage) {
+    typedef FusedCfg<TR, LIST, LEVEL, TI, TJ> C;
+    if constexpr (C::ok) {
+        FusedGroupImpl fg;
+        fg.first_stage = first_stage; fg.last_stage = last_stage; fg.n_parts = LIST::N;
+        fg.lds_bytes = C::lds_bytes; fg.threads = NT; fg.ti = TI; fg.tj = TJ; fg.n_slots = C::tab.n_slots;
+        for (int v = 0; v < TR::n_vars && v < FUSED_MAX_VARS; v++) fg.n_scratch_vars += C::tab.first[v] >= 0;
+        fg.launch = &launch_fused2d<TR, LIST, LEVEL, TI, TJ, NT>;
+        fg.func = reinterpret_cast<const void*>(&fused2d_kernel<TR, LIST, LEVEL, TI, TJ, NT>);
+        s.fused.push_back(fg);
+    }
+}
 template <class TR, class LIST, const int* LEVEL>
 void add_fused_group(SolnImpl& s, int first_stage, int last_stage) {
-    FusedGroupImpl fg;
-    fg.first_stage = first_stage; fg.last_stage = last_stage; fg.n_parts = LIST::N;
-    auto fill = [&](auto cfg, int ti, int tj, int nt, auto launch, const void* func) {
-        typedef decltype(cfg) C;
-        fg.lds_bytes = C::lds_bytes; fg.threads = nt; fg.ti = ti; fg.tj = tj; fg.n_slots = C::tab.n_slots;
-        for (int v = 0; v < TR::n_vars && v < FUSED_MAX_VARS; v++) fg.n_scratch_vars += C::tab.first[v] >= 0;
-        fg.launch = launch; fg.func = func;
-        s.fused.push_back(fg);
-    };
-    typedef FusedCfg<TR, LIST, LEVEL, 32, 64> C32;
-    typedef FusedCfg<TR, LIST, LEVEL, 16, 64> C16;
-    typedef FusedCfg<TR, LIST, LEVEL, 8, 64> C8;
-    // (the largest tile whose slots fit: a tile recomputes its halo ring -- swe2d, halos of 5 + 4: 1.46x the points at 32 x 64, 1.78x at
-    //  16 x 64; measured 2.27 against 2.80 ms per 4096^2 step, job r6g)
-    if constexpr (C32::ok)
-        fill(C32{}, 32, 64, 1024, &launch_fused2d<TR, LIST, LEVEL, 32, 64, 1024>, reinterpret_cast<const void*>(&fused2d_kernel<TR, LIST, LEVEL, 32, 64, 1024>));
-    else if constexpr (C16::ok)
-        fill(C16{}, 16, 64, 1024, &launch_fused2d<TR, LIST, LEVEL, 16, 64, 1024>, reinterpret_cast<const void*>(&fused2d_kernel<TR, LIST, LEVEL, 16, 64, 1024>));
-    else if constexpr (C8::ok)
-        fill(C8{}, 8, 64, 512, &launch_fused2d<TR, LIST, LEVEL, 8, 64, 512>, reinterpret_cast<const void*>(&fused2d_kernel<TR, LIST, LEVEL, 8, 64, 512>));
+#ifdef YKH_FUSED_TI
+    // (experiment builds: ONE tile shape named on the compiler's command line, e.g. -DYKH_FUSED_TI=24 -DYKH_FUSED_TJ=40)
+    add_fused_cfg<TR, LIST, LEVEL, YKH_FUSED_TI, YKH_FUSED_TJ, 1024>(s, first_stage, last_stage);
+    return;
+#endif
+    add_fused_cfg<TR, LIST, LEVEL, 32, 64, 1024>(s, first_stage, last_stage);
+    add_fused_cfg<TR, LIST, LEVEL, 32, 32, 1024>(s, first_stage, last_stage);
+    add_fused_cfg<TR, LIST, LEVEL, 16, 64, 1024>(s, first_stage, last_stage);
+    add_fused_cfg<TR, LIST, LEVEL, 8, 64, 512>(s, first_stage, last_stage);
 }
 
 }  // namespace ykh

@@ -220,8 +220,10 @@ bool Solution::fused_ok_at(const FusedGroupImpl& fg, idx_t t) const {
     return true;
 }
 const FusedGroupImpl* Solution::fused_group_at(int stage) const {
+    auto it = fused_pick_.find(stage);
+    if (it != fused_pick_.end()) return &impl.fused[(size_t)it->second];
     for (auto& fg : impl.fused)
-        if (fg.first_stage == stage) return &fg;
+        if (fg.first_stage == stage) return &fg;              // (no timing yet: the first registered = the largest tile)
     return nullptr;
 }
 void Solution::drop_fused_args() {
@@ -471,7 +473,7 @@ void Solution::tune_variants(bool quick, bool fresh_storage) {
         }
     }
     // fused scratch groups (ykh_fused.hpp) against one sweep per part: a whole step each way, the faster is kept
-    if (fused_usable() && fuse_scratch_mode < 0) {
+    if (fused_usable() && fuse_scratch_mode != 0) {
         auto step_ms_of = [&](bool fused) -> double {
             fused_on = fused;
             if (fused) ensure_fused_args();
@@ -486,7 +488,20 @@ void Solution::tune_variants(bool quick, bool fresh_storage) {
             if (many) per = (double)env->max_over_ranks((long long)(per * 1e6)) * 1e-6;
             return per;
         };
-        const double plain = step_ms_of(false), fused = step_ms_of(true);
+        const double plain = fuse_scratch_mode < 0 ? step_ms_of(false) : 1e30;        // (YASK_HIP_FUSE_SCRATCH=1: fused whatever the sweeps take)
+        // every registered tile shape of every group, one group at a time (the others on their current shape)
+        fused_pick_.clear();
+        double fused = step_ms_of(true);
+        for (size_t gi = 0; gi < impl.fused.size(); gi++) {
+            const int st = impl.fused[gi].first_stage;
+            if (fused_group_at(st) == &impl.fused[gi]) continue;              // (the shape just timed)
+            const auto before = fused_pick_;
+            fused_pick_[st] = (int)gi;
+            const double ms = step_ms_of(true);
+            if (env->trace) fprintf(stderr, "auto-tuner: fused group at stage %d, tile %d x %d: %.4f ms per step\n", st, impl.fused[gi].ti, impl.fused[gi].tj, ms);
+            if (ms < fused * 0.98) fused = ms;
+            else fused_pick_ = before;
+        }
         fused_on = fused < plain;
         if (env->trace) fprintf(stderr, "auto-tuner: a step with one sweep per part %.4f ms, with fused scratch groups %.4f ms -> %s\n", plain, fused,
                                 fused_on ? "fused" : "per part");
