@@ -202,6 +202,8 @@ __device__ __forceinline__ void fused_part(const PartArgs* __restrict__ args, co
     const bool ring = a.nxc == 2;
     const int hi0 = ring ? a.ax0 : 0, hi1 = ring ? a.ax1 : 0, hj0 = ring ? a.ay0 : 0, hj1 = ring ? a.ay1 : 0;
     if (ring && ri0 >= hi0 && ri0 + RI <= hi1 && rj0 >= hj0 && rj0 + RJ <= hj1) return;      // the tile's region lies in the hole
+    // (unrolled: the 1-3 iterations of a thread interleave their LDS reads; swe2d 1.72 -> 1.69 ms, wave2d 0.360 -> 0.343, same-box A/B r6z)
+#pragma unroll
     for (int idx = threadIdx.x; idx < RI * RJ; idx += NT) {
         const int i = ri0 + idx / RJ, j = rj0 + idx % RJ;
         const int in_box = min(min(i - bi0, bi1 - 1 - i), min(j - bj0, bj1 - 1 - j));         // >= 0: inside the part's box
