@@ -177,8 +177,19 @@ constexpr FusedGrow fused_grow() {
     return g;
 }
 
-template <class TR, class C, const int* LEVEL, int TI, int TJ, int NT, int K, class P>
-__device__ __forceinline__ void fused_part(const PartArgs* __restrict__ args, const FusedGeom& g, typename TR::real_t* lds, int ti0, int tj0) {
+// the words of a part's PartArgs the kernel needs before it can do anything: its box, the flag, the hole.  Fetched one part AHEAD
+// (fused_part): each part otherwise starts with scalar loads and a wait for them.
+struct FusedBoxWords { int x0, x1, y0, y1, nxc, hx0, hx1, hy0, hy1; };
+__device__ __forceinline__ FusedBoxWords fused_box_words(const PartArgs& a) { return {a.x0, a.x1, a.y0, a.y1, a.nxc, a.ax0, a.ax1, a.ay0, a.ay1}; }
+
+template <class TR, class C, const int* LEVEL, int TI, int TJ, int NT, int NPARTS, int K, class P>
+__device__ __forceinline__ void fused_part(const PartArgs* __restrict__ args, const FusedGeom& g, typename TR::real_t* lds, int ti0, int tj0,
+                                           FusedBoxWords& ahead) {
+    // (Same-box A/B, job r6za: with these nine words loaded at the top of the part -- BEFORE the level's barrier instead of behind it --
+    //  swe2d went 1.69 -> 1.55 ms and wave2d 0.343 -> 0.324: the loads travel while the workgroup waits at the barrier; fetched one
+    //  part ahead, 1.53 / 0.318.)
+    const FusedBoxWords bw = ahead;
+    if constexpr (K + 1 < NPARTS) ahead = fused_box_words(args[K + 1]);
     if constexpr (K > 0) {
         if constexpr (LEVEL[K] != LEVEL[K - 1]) __syncthreads();      // the next level reads what this one wrote (and may re-use its slots)
     }
@@ -190,7 +201,7 @@ __device__ __forceinline__ void fused_part(const PartArgs* __restrict__ args, co
     // a.nxc != 0: the condition holds at every point of that box -- nothing to evaluate per point (most parts: 64-bit index
     // comparisons per point cost more than the equations of a boundary strip).  A tile the box does not reach skips the part.
     const int ri0 = ti0 - gr.l0, rj0 = tj0 - gr.l1;
-    const int bi0 = a.x0, bi1 = a.x1, bj0 = a.y0, bj1 = a.y1;                     // (uniform: scalar loads)
+    const int bi0 = bw.x0, bi1 = bw.x1, bj0 = bw.y0, bj1 = bw.y1;                 // (uniform: scalar loads)
     if (bi0 >= ri0 + RI || bi1 <= ri0 || bj0 >= rj0 + RJ || bj1 <= rj0) return;
     // a.nxc == 2: a ring -- the condition holds in the box except in the hole [ax0, ax1) x [ay0, ay1) (both verified solid by the host;
     // any other part gets an empty hole, so that one test serves all).
@@ -198,9 +209,9 @@ __device__ __forceinline__ void fused_part(const PartArgs* __restrict__ args, co
     // chain of compares -- every compare result is a lane mask in SGPRs and every && of two masks a scalar instruction; the first
     // version of this loop issued twice as many scalar as vector instructions (7 336 against 3 556 for swe2d's 65 parts) and was bound by
     // the CU's one scalar issue per cycle.
-    const bool solid = a.nxc != 0;
-    const bool ring = a.nxc == 2;
-    const int hi0 = ring ? a.ax0 : 0, hi1 = ring ? a.ax1 : 0, hj0 = ring ? a.ay0 : 0, hj1 = ring ? a.ay1 : 0;
+    const bool solid = bw.nxc != 0;
+    const bool ring = bw.nxc == 2;
+    const int hi0 = ring ? bw.hx0 : 0, hi1 = ring ? bw.hx1 : 0, hj0 = ring ? bw.hy0 : 0, hj1 = ring ? bw.hy1 : 0;
     if (ring && ri0 >= hi0 && ri0 + RI <= hi1 && rj0 >= hj0 && rj0 + RJ <= hj1) return;      // the tile's region lies in the hole
     // (unrolled: the 1-3 iterations of a thread interleave their LDS reads; swe2d 1.72 -> 1.69 ms, wave2d 0.360 -> 0.343, same-box A/B r6z)
 #pragma unroll
@@ -221,7 +232,8 @@ __device__ __forceinline__ void fused_part(const PartArgs* __restrict__ args, co
 template <class TR, class C, const int* LEVEL, int TI, int TJ, int NT, class... Ps, int... Ks>
 __device__ __forceinline__ void fused_all(const PartArgs* __restrict__ args, const FusedGeom& g, typename TR::real_t* lds, int ti0, int tj0,
                                           PartList<Ps...>, std::integer_sequence<int, Ks...>) {
-    (fused_part<TR, C, LEVEL, TI, TJ, NT, Ks, Ps>(args, g, lds, ti0, tj0), ...);
+    FusedBoxWords ahead = fused_box_words(args[0]);
+    (fused_part<TR, C, LEVEL, TI, TJ, NT, (int)sizeof...(Ps), Ks, Ps>(args, g, lds, ti0, tj0, ahead), ...);
 }
 
 template <class TR, class LIST, const int* LEVEL, int TI, int TJ, int NT>
