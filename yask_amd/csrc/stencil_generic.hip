@@ -138,6 +138,23 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
                     p.default_variant = (int)p.variants.size() - 1;
                     p.variants.push_back(march_variant<P, VZ, 32, 16, 2, 1, false, 1, 3 | 4>());
                 }
+                // + late refill of the centre-only operands (_lo: each is held once instead of twice, ykh_march.hpp FL & 128) for parts
+                // that have several: awp's velocity part 256 VGPRs + 20 B of scratch -> 231, 1.61 -> 1.34 ms at 512^3; awp_elastic's
+                // stress part (8-byte lanes only without it) 2.62 -> 1.83; ssg2 -5 / -2 %; awp's stress part with 8-byte lanes 212 ->
+                // 166 VGPRs, 3.92 -> 3.77 (job r6zd; planes two ahead, two workgroups per CU, stores inside eval(): no gain, r6zc / r6zd)
+                if constexpr (march_once_count<P>() >= 3) {
+                    if constexpr (MarchCfg<P, 2, 64, 8>::lds_bytes <= 160 * 1024 && VZ > 2)
+                        p.variants.push_back(march_variant<P, 2, 64, 8, 2, 1, false, 1, 1 | 128>());
+                    if constexpr (VZ > 2 && MarchCfg<P, VZ, 32, 16>::lds_bytes <= 160 * 1024) {
+                        p.variants.push_back(march_variant<P, VZ, 32, 16, 2, 1, false, 1, 1 | 128>());
+                        p.variants.push_back(march_variant<P, VZ, 32, 16, 2, 1, false, 1, 1 | 4 | 128>());
+                    }
+                    if constexpr (VZ > 2 && MarchCfg<P, VZ, 32, 16, 1, true>::RING_TOT > 0 &&
+                                  MarchCfg<P, VZ, 32, 16, 1, true>::lds_bytes <= 160 * 1024) {
+                        p.variants.push_back(march_variant<P, VZ, 32, 16, 2, 1, false, 1, 3 | 128>());
+                        p.variants.push_back(march_variant<P, VZ, 32, 16, 2, 1, false, 1, 3 | 4 | 128>());
+                    }
+                }
             }
             add_box_family<P>(p, "", true);       // plane-ring shapes for box / plane neighbourhoods (above)
             // big bundles (fsg: 12 and 24 equations, 296 / 435 reads): the part as K clusters of equations, one launch each

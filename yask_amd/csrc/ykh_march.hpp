@@ -136,6 +136,17 @@ struct MarchCfg {
     static constexpr int XOVER = (max_nq() + 1) / 2 + 1;
 };
 
+// centre-only operands of a part that live in no slab and no mixed read ("once" operands: read once, by one thread) -- what the
+// late refill (_lo, FL & 128) holds once instead of twice
+template <class P>
+constexpr int march_once_count() {
+    typedef MarchCfg<P, 4, 32, 16> C;
+    int n = 0;
+    for (int g = 0; g < C::NG; g++)
+        if (C::tab.nq[g] == 1 && !C::tab.slab[g] && !C::tab.in_mix[g]) n++;
+    return n;
+}
+
 // PIN: honour the generated code's pin() after every temporary (strict program order: smallest live
 // ranges, least instruction-level parallelism); otherwise only the equations are kept sequential.
 // OPS: how the generated code's a - b and a / b are issued (fp32, VZ a multiple of 2):
