@@ -604,6 +604,19 @@ namespace yask {
                     os << (g ? ", " : "") << (nd == nddims ? "true" : "false");
                 }
                 os << "};\n";
+                // which of the kernels' domain dims each group's var has (bit 0 = x, the marching dim ... bit 2 = z, the unit-stride dim;
+                // 3-D solutions, else 7): an operand without x is loaded once per block, one without z is one value per row
+                os << "    static constexpr unsigned char group_dims[" << em.groups.size() << "] = {";
+                for (size_t g = 0; g < em.groups.size(); g++) {
+                    int mask = 0;
+                    for (auto& dim : em.groups[g].var->get_dims())
+                        if (dim->get_type() == DOMAIN_INDEX) {
+                            const int di = dc.domain_idx(dim->_get_name());
+                            if (di >= 0 && di < 3) mask |= 1 << di;
+                        }
+                    os << (g ? ", " : "") << (nddims == 3 ? mask : 7);
+                }
+                os << "};\n";
                 os << "    static constexpr int n_reads = " << em.reads.size() << ";\n"
                       "    static constexpr ReadOff reads[" << (em.reads.size() ? em.reads.size() : 1) << "] = {";
                 for (size_t i = 0; i < em.reads.size(); i++) {

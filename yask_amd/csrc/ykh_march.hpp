@@ -147,6 +147,12 @@ constexpr int march_once_count() {
     return n;
 }
 
+// a var over a subset of the domain dims that lacks the marching dim (awp's delta_t, h, cr_y, cr_z; iso3dfd_sponge's y and z
+// profiles): the same value at every plane -- loaded once per block into a register, never prefetched, queued or refilled.
+// (Such a var is read at the centre only: march_eligible() wants full vars wherever there is an offset.)
+template <class P>
+constexpr bool march_x_invariant(int g) { return !P::group_full[g] && (GroupDims<P>::get(g) & 1) == 0; }
+
 // PIN: honour the generated code's pin() after every temporary (strict program order: smallest live
 // ranges, least instruction-level parallelism); otherwise only the equations are kept sequential.
 // OPS: how the generated code's a - b and a / b are issued (fp32, VZ a multiple of 2):
@@ -171,6 +177,7 @@ struct MarchAcc {
     const V (&q)[C::NQTOT > 0 ? C::NQTOT : 1];     // queues of the row being evaluated
     const V (&mx)[C::NMIX > 0 ? C::NMIX : 1];      // mixed-offset reads of the row, prefetched
     const V (&nx)[C::NG];                          // prefetch registers of the row (LO: the "once" operands are read from here)
+    const V (&inv)[C::NG];                         // operands without the marching dim (march_x_invariant): loaded once per block
     const T* sb;            // current slab buffer set
     int ly, lz;             // row (within the tile) and z lane of the point
     int x, y, z0;           // point (first of the VZ)
@@ -206,6 +213,7 @@ struct MarchAcc {
             if constexpr (e == 0) return ldv<V>(pz);
             else return zshiftn<T, VZ, e>(ldv<V>(pz), ldv<V>(pz + VZ));
         } else if constexpr (DY == 0 && DZ == 0) {
+            if constexpr (march_x_invariant<P>(G)) return inv[G];
             if constexpr (LO && C::tab.nq[G] == 1 && !C::tab.slab[G] && !C::tab.in_mix[G]) return nx[G];
             constexpr int qi = C::tab.qoff[G] + (DX - C::tab.xlo[G] + PH) % C::tab.nq[G];
             return q[qi];
@@ -355,9 +363,20 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
             else return ldv_b<V>(sbase((const T*)a.ptr[g] + xplane(x)), ooff[j]);
         }
         else {
-            const T* p = (const T*)a.ptr[g] + (idx_t)xclamp(x) * a.gsx[g] + (idx_t)yc[j] * a.gsy[g];
-            if (a.gsz[g] == 0) return V(p[0]);
-            return ldv<V>(p + zc);
+            constexpr unsigned gd = GroupDims<P>::get(g);
+            if constexpr (gd == 7) {         // (no compile-time table: the run-time strides say which dims the var has)
+                const T* p = (const T*)a.ptr[g] + (idx_t)xclamp(x) * a.gsx[g] + (idx_t)yc[j] * a.gsy[g];
+                if (a.gsz[g] == 0) return V(p[0]);
+                return ldv<V>(p + zc);
+            } else {
+                // the dims the var has, known here: no stride multiplies for the others, ONE value where z is missing (a splat the
+                // compiler keeps in one register), a uniform address -- a scalar load -- where y and z are
+                const T* p = (const T*)a.ptr[g];
+                if constexpr ((gd & 1) != 0) p += (idx_t)xclamp(x) * a.gsx[g];
+                if constexpr ((gd & 2) != 0) p += (idx_t)yc[j] * a.gsy[g];
+                if constexpr ((gd & 4) == 0) return V(p[0]);
+                else return ldv<V>(p + zc);
+            }
         }
     };
     auto prefetch = [&](int x, auto sc) {      // everything needed to advance to centre plane x, into register set S
@@ -367,7 +386,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
             constexpr int NQ = C::tab.nq[g], XHI = C::tab.xlo[g] + C::tab.nq[g] - 1;
             constexpr bool slabg = C::tab.slab[g];
             constexpr bool once = NQ == 1 && !slabg && !C::tab.in_mix[g];
-            if constexpr (NQ > 0 && !(LO && once))
+            if constexpr (NQ > 0 && !(LO && once) && !march_x_invariant<P>(g))
                 static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; nxt[S][j][g] = ld_own(gc, j, x + XHI); });
             if constexpr (slabg) {
                 constexpr int NHT = C::tab.nht[g], HO = C::tab.hoff[g];
@@ -399,11 +418,18 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
             static_for<NG>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
                 constexpr bool once = C::tab.nq[g] == 1 && !C::tab.slab[g] && !C::tab.in_mix[g];
-                if constexpr (once)
+                if constexpr (once && !march_x_invariant<P>(g))
                     static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; nxt[S][j][g] = ld_own(gc, j, x + C::tab.xlo[g]); });
             });
     };
 
+    // operands without the marching dim: once per block
+    V inv[RY][NG];
+    static_for<NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (march_x_invariant<P>(g) && C::tab.nq[g] > 0)
+            static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; inv[j][g] = ld_own(gc, j, xs); });
+    });
     // prologue: queues hold planes xs+xlo .. xs+xhi-1; newest plane + halos of plane xs prefetched
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
@@ -439,7 +465,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
             constexpr int g = decltype(gc)::value;
             constexpr int NQ = C::tab.nq[g], QO = C::tab.qoff[g], XLO = C::tab.xlo[g];
             constexpr bool slabg = C::tab.slab[g];
-            if constexpr (NQ > 0 && !(LO && NQ == 1 && !slabg && !C::tab.in_mix[g]))
+            if constexpr (NQ > 0 && !(LO && NQ == 1 && !slabg && !C::tab.in_mix[g]) && !march_x_invariant<P>(g))
                 static_for<RY>([&](auto jc) { constexpr int j = decltype(jc)::value; q[j][QO + (NQ - 1 + PH) % NQ] = nxt[S][j][g]; });
             if constexpr (slabg) {
                 constexpr int YL = C::tab.yl[g], ZLV = C::tab.zlv[g], LP = C::tab.lp[g], SO = C::tab.soff[g];
@@ -475,7 +501,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) march_kernel(const PartArgs a)
             constexpr int j = decltype(jc)::value;
             const int myy = myy0 + j;
             V out[MAX_GROUPS];
-            MarchAcc<C, P, PIN, OPS, PH, LO> acc{a, q[j], mreg[S][j], nxt[S][j], sb, ly * RY + j, lz, x, myy, myz, out, m1};
+            MarchAcc<C, P, PIN, OPS, PH, LO> acc{a, q[j], mreg[S][j], nxt[S][j], inv[j], sb, ly * RY + j, lz, x, myy, myz, out, m1};
             P::eval(acc);
             if (x < xe && myy < a.y1 && myz < a.z1 && myz + VZ > a.z0) {
                 // (written groups are vars over all dims; the store predicate implies yc[j] == myy, zc == myz)

@@ -4,6 +4,7 @@
 // (src/compiler/lib/YaskKernel.cpp:730-1181 `print_context`): dims, vars, per-var halos,
 // step-slot counts, L1 norms, parts, stages and their dependencies.
 #pragma once
+#include <type_traits>
 
 namespace ykh {
 
@@ -48,6 +49,15 @@ struct AccessGroup {
     int misc[MAX_VAR_DIMS] = {};
     int dw = 0;                       // offset in the DIM_OUTER dim (0 unless the solution has 4 domain dims)
 };
+
+// Which of the kernels' three domain dims (bit 0 = x, the marching dim ... bit 2 = z, the unit-stride dim) the var of a part's access
+// group has, at compile time: the compiler target's `group_dims` (3-D solutions; parts without the table -- wrappers, hand-written
+// parts -- say 7 and get the run-time strides).  An operand without x is loaded once per block instead of once per plane, one
+// without z is one value per row instead of a vector, one with neither y nor z is uniform (a scalar load).
+template <class P, class = void>
+struct GroupDims { static constexpr unsigned get(int) { return 7; } };
+template <class P>
+struct GroupDims<P, std::void_t<decltype(P::group_dims)>> { static constexpr unsigned get(int g) { return P::group_dims[g]; } };
 
 struct ReadOff {
     signed char g;            // access-group index

@@ -362,6 +362,22 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
                     // own strides (0 for a missing dim); without the unit-stride dim the value is broadcast
                     // (operands without the marching dim -- iso3dfd_sponge's y and z profiles -- were loaded once, before the loop:
                     //  round 5; they used to be re-loaded every plane, two rows of 64-bit address arithmetic and a load each)
+                    constexpr unsigned gd = GroupDims<P>::get(g);
+                    if constexpr (gd != 7) {
+                        // the var's dims are known here (the compiler target's group_dims, round 6): operands without x live in
+                        // cinv[] (below) and are not touched per plane; no stride multiply for a missing dim, one value per row
+                        // where z is missing
+                        if constexpr ((gd & 1) != 0) {
+                            const int xg = (int)((pc - org) / a.sx);      // plane index (uniform)
+                            static_for<RY>([&](auto jc) {
+                                constexpr int j = decltype(jc)::value;
+                                const T* gp = (const T*)a.ptr[g] + (idx_t)xg * a.gsx[g];
+                                if constexpr ((gd & 2) != 0) gp += (idx_t)clampi(yt0 + ly * RY + j, a.ay0, a.ay1 - 1) * a.gsy[g];
+                                if constexpr ((gd & 4) == 0) cen[CS][g][j] = V(gp[0]);
+                                else cen[CS][g][j] = ldv<V>(gp + zc);
+                            });
+                        }
+                    } else
                     if (a.gsx[g] != 0) {
                     const int xg = (int)((pc - org) / a.sx);      // plane index (uniform)
                     static_for<RY>([&](auto jc) {
@@ -376,12 +392,29 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
             }
         });
     };
-    // partial-dim operands that do not depend on x: every operand set, once
+    // partial-dim operands that do not depend on x, known as such at compile time: ONE copy for every plane and operand set (the
+    // run-time form below keeps CD copies of each: 48 VGPRs for iso3dfd_sponge's three profiles in the headline's shape)
+    V cinv[NG][RY];
+    static_for<NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g != SG && analyze_group<P>(g).any && !P::group_full[g]) {
+            constexpr unsigned gd = GroupDims<P>::get(g);
+            if constexpr (gd != 7 && (gd & 1) == 0)
+                static_for<RY>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const T* gp = (const T*)a.ptr[g];
+                    if constexpr ((gd & 2) != 0) gp += (idx_t)clampi(yt0 + ly * RY + j, a.ay0, a.ay1 - 1) * a.gsy[g];
+                    if constexpr ((gd & 4) == 0) cinv[g][j] = V(gp[0]);
+                    else cinv[g][j] = ldv<V>(gp + zc);
+                });
+        }
+    });
+    // partial-dim operands that do not depend on x (run-time form): every operand set, once
     static_for<CD>([&](auto cs) {
         constexpr int CS = decltype(cs)::value;
         static_for<NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            if constexpr (g != SG && analyze_group<P>(g).any && !P::group_full[g]) {
+            if constexpr (g != SG && analyze_group<P>(g).any && !P::group_full[g] && GroupDims<P>::get(g) == 7) {
                 if (a.gsx[g] == 0)
                     static_for<RY>([&](auto jc) {
                         constexpr int j = decltype(jc)::value;
@@ -582,7 +615,10 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) starlin_kernel(const PartArgs 
             V cj[MAX_GROUPS], out[MAX_GROUPS];
             static_for<NG>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
-                if constexpr (g != SG && analyze_group<P>(g).any) cj[g] = cen[CS][g][j];
+                if constexpr (g != SG && analyze_group<P>(g).any) {
+                    if constexpr (!P::group_full[g] && GroupDims<P>::get(g) != 7 && (GroupDims<P>::get(g) & 1) == 0) cj[g] = cinv[g][j];
+                    else cj[g] = cen[CS][g][j];
+                }
             });
             LinAcc<C> la{pq[qo][j], cj, out};
             P::eval_lin(la, acc[ao][j]);

@@ -72,6 +72,7 @@ struct SubPart {
     static constexpr int n_groups = P::n_groups;
     static constexpr const AccessGroup (&groups)[P::n_groups] = P::groups;
     static constexpr const bool (&group_full)[P::n_groups] = P::group_full;
+    static constexpr const unsigned char (&group_dims)[P::n_groups] = P::group_dims;
     static constexpr SubPartTab<P, WM> tab = make_subpart_tab<P, WM>();
     static constexpr int n_reads = tab.n_reads;
     static constexpr const ReadOff (&reads)[P::n_reads > 0 ? P::n_reads : 1] = tab.reads;
