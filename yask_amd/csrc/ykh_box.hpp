@@ -225,6 +225,29 @@ struct BoxAcc {
         } else if constexpr (C::tab.kind[G] == 4) {
             // a var over a subset of the domain dims (its strides are 0 in the dims it lacks), read at an offset: every var shares the
             // solution's pads in the dims it has (Var::compute_geometry), so the clamps of the shared layout hold for it too
+            constexpr unsigned gd = GroupDims<P>::get(G);
+            if constexpr (gd != 7) {
+                // the table's dims at compile time (the compiler target's group_dims): no multiply for a dim it lacks, ONE value per
+                // row where it has no z (79 live 16-byte operands were what spilled test_partial_3d on every shape of this kernel)
+                const T* px = (const T*)a.ptr[G];
+                if constexpr ((gd & 1) != 0) px += (idx_t)clampi(x + DX, a.ax0, a.ax1 - 1) * a.gsx[G];
+                if constexpr ((gd & 4) == 0)
+                    return rows([&](auto jc) -> V1 {
+                        constexpr int j = decltype(jc)::value;
+                        if constexpr ((gd & 2) != 0) return V1(px[(idx_t)clampi(y + j + DY, a.ay0, a.ay1 - 1) * a.gsy[G]]);
+                        else return V1(px[0]);
+                    });
+                else {
+                    const int zl = clampi(z0 + qq * VZ, a.az0, a.az1 - VZ), zh = clampi(z0 + (qq + 1) * VZ, a.az0, a.az1 - VZ);
+                    return rows([&](auto jc) -> V1 {
+                        constexpr int j = decltype(jc)::value;
+                        const T* p = px;
+                        if constexpr ((gd & 2) != 0) p += (idx_t)clampi(y + j + DY, a.ay0, a.ay1 - 1) * a.gsy[G];
+                        if constexpr (e == 0) return ldv<V1>(p + zl);
+                        else return zshiftn<T, VZ, e>(ldv<V1>(p + zl), ldv<V1>(p + zh));
+                    });
+                }
+            }
             const T* px = (const T*)a.ptr[G] + (idx_t)clampi(x + DX, a.ax0, a.ax1 - 1) * a.gsx[G];
             if (a.gsz[G] == 0)          // no unit-stride dim: one value per row (uniform branch)
                 return rows([&](auto jc) -> V1 {

@@ -279,8 +279,19 @@ struct NaiveAcc {
             // same expression for every read of the group: one evaluation), the read's offset as a uniform term the scalar unit computes.
             // Written as (x + DX) * gsx + ... every read cost three 64-bit vector multiplies: test_partial_3d, 59 such reads per point,
             // spent more instructions on addresses than cube spends on its 125 additions (round 6).
-            const idx_t base = (idx_t)x * a.gsx[G] + (idx_t)y * a.gsy[G] + (idx_t)z * a.gsz[G];
-            return p[base + ((idx_t)DX * a.gsx[G] + (idx_t)DY * a.gsy[G] + (idx_t)DZ * a.gsz[G])];
+            constexpr unsigned gd = GroupDims<P>::get(G);
+            if constexpr (gd == 7) {
+                const idx_t base = (idx_t)x * a.gsx[G] + (idx_t)y * a.gsy[G] + (idx_t)z * a.gsz[G];
+                return p[base + ((idx_t)DX * a.gsx[G] + (idx_t)DY * a.gsy[G] + (idx_t)DZ * a.gsz[G])];
+            } else {
+                // the var's dims at compile time (the compiler target's group_dims): no multiply for a dim it lacks, none for z (a var
+                // that has the innermost domain dim has it at stride 1, Var::compute_geometry); an x-only table is a uniform address
+                idx_t o = 0;
+                if constexpr ((gd & 1) != 0) o += (idx_t)(x + DX) * a.gsx[G];
+                if constexpr ((gd & 2) != 0) o += (idx_t)(y + DY) * a.gsy[G];
+                if constexpr ((gd & 4) != 0) o += z + DZ;
+                return p[o];
+            }
         }
     }
     template <int G>

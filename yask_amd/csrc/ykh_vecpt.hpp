@@ -36,10 +36,20 @@ struct VecPtAcc {
             pz = ((const T*)a.ptr[G] + ((idx_t)DX * a.sx + (idx_t)DY * a.sy + q * VZ)) + c;
         else {
             // (the point's offset once per group, the read's offset as a uniform term: see NaiveAcc::rd)
-            const idx_t base = (idx_t)x * a.gsx[G] + (idx_t)y * a.gsy[G];
-            const T* p = (const T*)a.ptr[G] + base + ((idx_t)DX * a.gsx[G] + (idx_t)DY * a.gsy[G]);
-            if (a.gsz[G] == 0) return V(p[0]);                 // var without the unit-stride dim: broadcast
-            pz = p + z0 + q * VZ;
+            constexpr unsigned gd = GroupDims<P>::get(G);
+            if constexpr (gd == 7) {
+                const idx_t base = (idx_t)x * a.gsx[G] + (idx_t)y * a.gsy[G];
+                const T* p = (const T*)a.ptr[G] + base + ((idx_t)DX * a.gsx[G] + (idx_t)DY * a.gsy[G]);
+                if (a.gsz[G] == 0) return V(p[0]);                 // var without the unit-stride dim: broadcast
+                pz = p + z0 + q * VZ;
+            } else {
+                // (the var's dims at compile time, see NaiveAcc::rd: no multiply for a missing dim, no branch on the z stride)
+                const T* p = (const T*)a.ptr[G];
+                if constexpr ((gd & 1) != 0) p += (idx_t)(x + DX) * a.gsx[G];
+                if constexpr ((gd & 2) != 0) p += (idx_t)(y + DY) * a.gsy[G];
+                if constexpr ((gd & 4) == 0) return V(p[0]);
+                pz = p + z0 + q * VZ;
+            }
         }
         if constexpr (e == 0) return ldv<V>(pz);
         else return zshiftn<T, VZ, e>(ldv<V>(pz), ldv<V>(pz + VZ));
