@@ -30,6 +30,13 @@ constexpr bool starlin_eligible() {
 // chain of fp32 additions runs faster as v_pk_add_f32 (~10 VALU cycles per wave) or as two v_add_f32 (4 each) depends on the part
 // (cube, 3axis_with_diags, tti: plain adds; 3plane: packed; profiles/r5_box): prepare_solution()'s timing decides per part -- there is
 // no list of solution names in the build any more.
+// Which parts get plane-ring shapes: more mixed-offset reads than the marching kernel prefetches (MAX_MIXED: cube, 3plane, tti ...), or
+// a small part that is MOSTLY mixed reads -- the reference's test_3d / test_stages_3d / test_boundary_3d read the 8 corners of a box
+// (-2..4, -6..5, -4..3) around the point: on the point kernel every corner plane crosses the fabric again 6 planes later (test_3d
+// 0.353 ms at 512^3), with the 7 planes in an LDS ring 0.241 (job r6zl).
+template <class P>
+constexpr bool box_wanted() { return count_mixed<P>() > MAX_MIXED || (count_mixed<P>() >= 4 && 2 * count_mixed<P>() + 1 >= P::n_reads); }
+
 template <class P>
 struct NoPk : P {};
 inline const char* keep_name(const std::string& n) {
@@ -47,7 +54,7 @@ void add_box_family(PartImpl& p, const char* suffix, bool set_default) {
     // Tile 128 x 16 points (fp32; 16-byte lanes): 512 threads with one row each, or 256 threads with two rows each evaluated as one
     // wide vector (shared LDS rows are loaded once; needs ~230 VGPRs); _p2 = planes requested two iterations ahead; _w1 = one
     // wave per SIMD with the whole register file, for parts like tti (340 VGPRs on any kernel).  prepare_solution() times them.
-    if constexpr (box_eligible<Q>() && count_mixed<Q>() > MAX_MIXED) {
+    if constexpr (box_eligible<Q>() && box_wanted<Q>()) {
         constexpr int TZL = 32;          // (z tile = 32 lanes of 16 bytes)
         if constexpr (2 * BoxCfg<Q, VZ, TZL, 16, 1>::ring_reads() >= Q::n_reads) {
             p.variants.push_back(box_variant<Q, VZ, TZL, 16, 1, 2, 1>());
@@ -216,7 +223,7 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
             lifted(vecpt_variant<L, VZ, 64, 4, 1>());
             p.default_variant = (int)p.variants.size() - 1;
             lifted(vecpt_variant<L, VZ, 16, 16, 1>());          // (64 x 16-point tile: thin boxes, short rows)
-            if constexpr (box_eligible<L>() && count_mixed<L>() > MAX_MIXED) {
+            if constexpr (box_eligible<L>() && box_wanted<L>()) {
                 if constexpr (2 * BoxCfg<L, VZ, 32, 16, 1>::ring_reads() >= L::n_reads) lifted(box_variant<L, VZ, 32, 16, 1, 2, 1>());
             }
         }
