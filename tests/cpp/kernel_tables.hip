@@ -29,6 +29,10 @@ void part(const char* name, bool first) {
            "  \"box_128x16\": {\"lds\": %zu, \"ring_reads\": %d, \"xover\": %d}, \"box_128x8_80k\": {\"lds\": %zu, \"ring_reads\": %d}, \"box_128x8\": {\"lds\": %zu, \"ring_reads\": %d}",
            first ? "" : ",\n", name, P::n_groups, P::n_reads, P::n_writes, count_mixed<P>(), (int)box_eligible<P>(), (int)march_eligible<P>(),
            B16::lds_bytes, B16::ring_reads(), B16::XOVER, B8h::lds_bytes, B8h::ring_reads(), B8::lds_bytes, B8::ring_reads());
+    // round 6, second half: the plane-ring rule, the centre-only operands the late refill (_lo) holds once, the operands loaded once per block
+    int xinv = 0;
+    for (int g = 0; g < P::n_groups; g++) xinv += march_x_invariant<P>(g) ? 1 : 0;
+    printf(", \"box_wanted\": %d, \"once\": %d, \"x_invariant\": %d", (int)box_wanted<P>(), march_once_count<P>(), xinv);
     clusters<P, 2>(", ");
     clusters<P, 4>(", ");
     // the part lifted to one x plane (ykh_lift2d.hpp: what a 2-D solution's parts are given to the 3-D kernel families as)

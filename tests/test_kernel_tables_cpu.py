@@ -111,3 +111,22 @@ def test_fused_scratch_group_plans(tmp_path):
     for soln in ("wave2d", "swe2d", "test_scratch_2d", "test_scratch_1d", "test_scratch_stages_1d", "test_scratch_boundary_1d"):
         for g in fused_tables(tmp_path, soln):
             assert g["slot_conflicts"] == 0 and g["unassigned"] == 0, (soln, g)
+
+
+def test_round6_registry_rules(tmp_path):
+    """Second half of round 6: which parts get plane-ring shapes (more than MAX_MIXED mixed reads, or >= 4 that are at least half of
+    the reads), how many centre-only operands the late refill holds once (>= 3: `_lo` shapes are registered), and which partial-dim
+    operands the compiler target's `group_dims` lets the marching kernel load once per block."""
+    t3 = tables(tmp_path, "test_3d")["part_1"]
+    assert (t3["reads"], t3["mixed"], t3["box_wanted"]) == (9, 8, 1)          # the 8 corners of a box: exactly MAX_MIXED
+    assert tables(tmp_path, "iso3dfd")["part_1"]["box_wanted"] == 0
+    assert tables(tmp_path, "cube")["part_1"]["box_wanted"] == 1
+    awp = tables(tmp_path, "awp")
+    v, s = awp["part_1"], awp["part_2"]
+    assert v["box_wanted"] == 0 and s["box_wanted"] == 0                        # 3 / 8 mixed reads among 48 / 70
+    assert v["once"] >= 3 and s["once"] >= 12                                   # vel(t) + the five partial-dim vars; stress + memory vars + coefficients
+    assert v["x_invariant"] == 4 and s["x_invariant"] == 4                      # delta_t, h, cr_y, cr_z (cr_x has the marching dim)
+    sp = tables(tmp_path, "iso3dfd_sponge")["part_1"]
+    assert sp["x_invariant"] == 2                                               # cr_y, cr_z
+    assert tables(tmp_path, "ssg")["part_1"]["x_invariant"] == 0                # every group a 3-D var
+

@@ -30,13 +30,6 @@ constexpr bool starlin_eligible() {
 // chain of fp32 additions runs faster as v_pk_add_f32 (~10 VALU cycles per wave) or as two v_add_f32 (4 each) depends on the part
 // (cube, 3axis_with_diags, tti: plain adds; 3plane: packed; profiles/r5_box): prepare_solution()'s timing decides per part -- there is
 // no list of solution names in the build any more.
-// Which parts get plane-ring shapes: more mixed-offset reads than the marching kernel prefetches (MAX_MIXED: cube, 3plane, tti ...), or
-// a small part that is MOSTLY mixed reads -- the reference's test_3d / test_stages_3d / test_boundary_3d read the 8 corners of a box
-// (-2..4, -6..5, -4..3) around the point: on the point kernel every corner plane crosses the fabric again 6 planes later (test_3d
-// 0.353 ms at 512^3), with the 7 planes in an LDS ring 0.241 (job r6zl).
-template <class P>
-constexpr bool box_wanted() { return count_mixed<P>() > MAX_MIXED || (count_mixed<P>() >= 4 && 2 * count_mixed<P>() + 1 >= P::n_reads); }
-
 template <class P>
 struct NoPk : P {};
 inline const char* keep_name(const std::string& n) {

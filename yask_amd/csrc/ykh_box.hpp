@@ -59,6 +59,12 @@ constexpr int count_mixed() {
     }
     return n;
 }
+// Which parts get plane-ring shapes: more mixed-offset reads than the marching kernel prefetches (MAX_MIXED: cube, 3plane, tti ...), or
+// a small part that is MOSTLY mixed reads -- the reference's test_3d / test_stages_3d / test_boundary_3d read the 8 corners of a box
+// (-2..4, -6..5, -4..3) around the point: on the point kernel every corner plane crosses the fabric again 6 planes later (test_3d
+// 0.353 ms at 512^3), with the 7 planes in an LDS ring 0.241 (job r6zl).
+template <class P>
+constexpr bool box_wanted() { return count_mixed<P>() > MAX_MIXED || (count_mixed<P>() >= 4 && 2 * count_mixed<P>() + 1 >= P::n_reads); }
 // Written groups are vars over all domain dims (shared strides / pads).  Groups read at an offset may be vars over a SUBSET of the
 // domain dims since round 6 (test_partial_3d: 1-D and 2-D coefficient tables read at offsets): they never get a ring -- a table
 // that lacks a dim is small and stays in the L1 / L2 -- and are loaded where they are used through their own strides (kind 4).
