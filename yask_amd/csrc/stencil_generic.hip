@@ -85,7 +85,7 @@ void add_box_family(PartImpl& p, const char* suffix, bool set_default) {
 // ---- the second translation unit of a solution with box / plane neighbourhoods: compiled with -target-feature -packed-fp32-ops
 template <class P>
 void add_np_part(PartImpl& p, int ndd) {
-    if (ndd == 3) add_box_family<NoPk<P>>(p, "_np", false);
+    if (ndd == 3 || ndd == 4) add_box_family<NoPk<P>>(p, "_np", false);
 }
 void ykh_add_np_variants(SolnImpl& s, int ndd) {
     using namespace YKH_GEN_NS;
@@ -108,7 +108,10 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
     // Sub-domain parts get the same kernels: they do not evaluate the condition, and prepare_solution() selects
     // them only when the condition holds at every point of its bounding box (a "solid" box, e.g. awp's
     // below-the-surface updates); otherwise the point kernel runs.
-    if (ndd == 3) {
+    // (four domain dims -- test_4d: the outermost one is a loop of launches with shifted base pointers, Solution::launch_part; each launch
+    //  sweeps the inner three with any family below, the access groups telling the outer offsets apart.  Until the end of round 6 such
+    //  solutions got the point kernels only.)
+    if (ndd == 3 || ndd == 4) {
         {
             p.variants.push_back(vecpt_variant<P, VZ, 64, 4, 1>());
             p.default_variant = (int)p.variants.size() - 1;
@@ -193,11 +196,6 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
                 }
             }
         }
-    } else if (ndd == 4) {
-        // four domain dims (test_4d): the outermost one is a loop of launches with shifted base pointers (Solution::launch_part), each
-        // launch sweeps the inner three -- with the vector point kernel too since round 6 (was: scalar point kernel only)
-        p.variants.push_back(vecpt_variant<P, VZ, 64, 4, 1>());
-        p.default_variant = (int)p.variants.size() - 1;
     } else if (ndd == 1) {
         // one domain dim: the vector point kernel on the part lifted to one row of one plane (ykh_lift2d.hpp, SHIFT = 2)
         if constexpr (lift2d_shape<P, 2>()) {
