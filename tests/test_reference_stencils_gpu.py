@@ -117,6 +117,31 @@ def test_generic_registry_picks_fast_shapes(gpu):
     assert s.get_kernel_variant(0).split("_")[0] in ("starlin", "march"), s.get_kernel_variant(0)
 
 
+def test_round6_candidates_are_registered(gpu):
+    """Second half of round 6: parts with several centre-only operands get late-refill (`_lo`) marching shapes, small parts
+    that are mostly mixed-offset reads get plane-ring shapes, and a solution with four domain dims gets the 3-D families on each launch
+    of its outer loop -- as CANDIDATES of prepare_solution()'s timing (which one wins is the clock's business and is held to 1.5x of the
+    best above; every one of them is held to the reference's outputs by the fixture tests, which run every registered shape)."""
+    from yask_amd import yk_factory
+
+    def names(stencil, part):
+        fac = yk_factory(stencil)
+        s = fac.new_solution(fac.new_env())
+        s.set_overall_domain_size_vec([64] * len(s.get_domain_dim_names()))
+        s.prepare_solution()
+        return s.get_kernel_variant_names(part)
+
+    for part in (0, 1):
+        n = names("awp", part)
+        assert "march_v4_z128_y16_nt_lo_w2" in n and "march_v2_z128_y8_nt_lo_w2" in n and "march_v4_z128_y16_nt_ps_lo_w2" in n, n
+    assert any(v.startswith("march_") and "_lo_" in v for v in names("iso3dfd_sponge", 0))
+    assert not any("_lo_" in v for v in names("test_stream_3d", 0))          # (two centre-only operands: below the rule's three)
+    for stencil in ("test_3d", "test_stages_3d", "test_boundary_3d", "cube", "test_4d"):
+        assert any(v.startswith("box_") for v in names(stencil, 0)), stencil
+    assert not any(v.startswith("box_") for v in names("awp", 1))              # 8 mixed reads among 70: the marching kernel's business
+    assert any(v.startswith("march_") for v in names("test_4d", 0))
+
+
 def test_sub_domain_parts_get_bounding_boxes(gpu):
     """prepare_solution() finds, on the device, the bounding box of every IF_DOMAIN condition inside the rank
     (the reference's find_bounding_box, setup.cpp:1082-1169) and launches the part only there.
