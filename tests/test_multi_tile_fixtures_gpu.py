@@ -173,9 +173,14 @@ def _rank_worker(rank, world, port, name, nr, q):
         idx = [O.lattice(n, **meta["lattice"]) for n in meta["size"]]
         mine = [ix[(ix >= f[d]) & (ix <= l[d])] for d, ix in enumerate(idx)]
         var = s.get_var(vname)
-        a = np.empty(tuple(len(m) for m in mine), dtype=np.float64)
+        # (trailing misc dims -- ssg2: v(t, x, y, z, vidx) -- are kept whole, as in _lattice_of)
+        misc = [d for d in var.get_dim_names()[4:]]
+        m0 = [var.get_first_misc_index(d) for d in misc]
+        m1 = [var.get_last_misc_index(d) for d in misc]
+        mshape = tuple(b - a_ + 1 for a_, b in zip(m0, m1))
+        a = np.empty(tuple(len(m) for m in mine) + mshape, dtype=np.float64)
         for k, x in enumerate(mine[0]):
-            pl = np.asarray(var.get_elements_in_slice([t, int(x), f[1], f[2]], [t, int(x), l[1], l[2]])).reshape(l[1] - f[1] + 1, l[2] - f[2] + 1)
+            pl = np.asarray(var.get_elements_in_slice([t, int(x), f[1], f[2]] + m0, [t, int(x), l[1], l[2]] + m1)).reshape((l[1] - f[1] + 1, l[2] - f[2] + 1) + mshape)
             a[k] = pl[mine[1] - f[1]][:, mine[2] - f[2]]
         out[key] = (mine, a)
     q.put((rank, out, [s.get_kernel_variant(p) for p in range(s.get_num_parts())]))
@@ -184,10 +189,12 @@ def _rank_worker(rank, world, port, name, nr, q):
 
 
 @pytest.mark.parametrize("world,nr", [(2, (2, 1, 1)), (8, (2, 2, 2))], ids=["2ranks", "8ranks"])
-@pytest.mark.parametrize("stencil", ["cube", "fsg_abc"])
+@pytest.mark.parametrize("stencil", ["cube", "fsg_abc", "awp", "ssg2", "iso3dfd_sponge"])
 def test_decomposed_runs_match_the_reference_fixture(gpu, stencil, world, nr):
     """N ranks on one device (IPC transport): the assembled lattice equals the REFERENCE's one-rank result at that size -- the checker
-    is the fixture, not this library's own one-rank run (which tests/test_part_boxes_gpu.py and test_clusters_gpu.py compare bit for bit)."""
+    is the fixture, not this library's own one-rank run (which tests/test_part_boxes_gpu.py and test_clusters_gpu.py compare bit for bit).
+    awp / ssg2 / iso3dfd_sponge (end of round 6): one-part stages on generic marching shapes, which now have descriptor-reading twins --
+    over 2 x 2 x 2 ranks they run the planned / halves schedules instead of exterior slabs + interior."""
     import multiprocessing as mp
     name = [n for n in CASES if INDEX[n]["stencil"] == stencil][0]
     meta = INDEX[name]

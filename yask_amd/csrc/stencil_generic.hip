@@ -122,24 +122,24 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
             if constexpr (march_eligible<P>() && P::n_groups <= 48) {
                 // 8-byte lanes keep the per-thread queue state small (ykh_march.hpp); tile 128 x 8
                 if constexpr (MarchCfg<P, 2, 64, 8>::lds_bytes <= 160 * 1024) {
-                    p.variants.push_back(march_variant<P, 2, 64, 8, 2>());
+                    p.variants.push_back(march_variant_planned<P, 2, 64, 8, 2>());
                     p.default_variant = (int)p.variants.size() - 1;
                 }
                 // 16-byte lanes, tile 128 x 16, one-touch streams non-temporal: fastest where the state still fits
                 // 256 VGPRs (ssg: +12 %); prepare_solution() steps back to the shape above when this one spilled
                 if constexpr (VZ > 2 && MarchCfg<P, VZ, 32, 16>::lds_bytes <= 160 * 1024) {
-                    p.variants.push_back(march_variant<P, VZ, 32, 16, 2, 1, false, 1, 1>());
+                    p.variants.push_back(march_variant_planned<P, VZ, 32, 16, 2, 1, false, 1, 1>());
                     p.default_variant = (int)p.variants.size() - 1;
                     // + packed subtractions (exact: a - b as fma(b, -1, a); ssg stage 1: -2.8 %) -- another candidate for
                     // the timing pass of prepare_solution(), which also drops it where the different schedule spills
-                    p.variants.push_back(march_variant<P, VZ, 32, 16, 2, 1, false, 1, 1 | 4>());
+                    p.variants.push_back(march_variant_planned<P, VZ, 32, 16, 2, 1, false, 1, 1 | 4>());
                 }
                 // + halo rings where a group has both a queue reaching ahead and a slab (ykh_march.hpp, HR)
                 if constexpr (VZ > 2 && MarchCfg<P, VZ, 32, 16, 1, true>::RING_TOT > 0 &&
                               MarchCfg<P, VZ, 32, 16, 1, true>::lds_bytes <= 160 * 1024) {
-                    p.variants.push_back(march_variant<P, VZ, 32, 16, 2, 1, false, 1, 3>());
+                    p.variants.push_back(march_variant_planned<P, VZ, 32, 16, 2, 1, false, 1, 3>());
                     p.default_variant = (int)p.variants.size() - 1;
-                    p.variants.push_back(march_variant<P, VZ, 32, 16, 2, 1, false, 1, 3 | 4>());
+                    p.variants.push_back(march_variant_planned<P, VZ, 32, 16, 2, 1, false, 1, 3 | 4>());
                 }
                 // + late refill of the centre-only operands (_lo: each is held once instead of twice, ykh_march.hpp FL & 128) for parts
                 // that have several: awp's velocity part 256 VGPRs + 20 B of scratch -> 231, 1.61 -> 1.34 ms at 512^3; awp_elastic's
@@ -147,15 +147,15 @@ void add_part(SolnImpl& s, const PartMeta* meta, int ndd) {
                 // 166 VGPRs, 3.92 -> 3.77 (job r6zd; planes two ahead, two workgroups per CU, stores inside eval(): no gain, r6zc / r6zd)
                 if constexpr (march_once_count<P>() >= 3) {
                     if constexpr (MarchCfg<P, 2, 64, 8>::lds_bytes <= 160 * 1024 && VZ > 2)
-                        p.variants.push_back(march_variant<P, 2, 64, 8, 2, 1, false, 1, 1 | 128>());
+                        p.variants.push_back(march_variant_planned<P, 2, 64, 8, 2, 1, false, 1, 1 | 128>());
                     if constexpr (VZ > 2 && MarchCfg<P, VZ, 32, 16>::lds_bytes <= 160 * 1024) {
-                        p.variants.push_back(march_variant<P, VZ, 32, 16, 2, 1, false, 1, 1 | 128>());
-                        p.variants.push_back(march_variant<P, VZ, 32, 16, 2, 1, false, 1, 1 | 4 | 128>());
+                        p.variants.push_back(march_variant_planned<P, VZ, 32, 16, 2, 1, false, 1, 1 | 128>());
+                        p.variants.push_back(march_variant_planned<P, VZ, 32, 16, 2, 1, false, 1, 1 | 4 | 128>());
                     }
                     if constexpr (VZ > 2 && MarchCfg<P, VZ, 32, 16, 1, true>::RING_TOT > 0 &&
                                   MarchCfg<P, VZ, 32, 16, 1, true>::lds_bytes <= 160 * 1024) {
-                        p.variants.push_back(march_variant<P, VZ, 32, 16, 2, 1, false, 1, 3 | 128>());
-                        p.variants.push_back(march_variant<P, VZ, 32, 16, 2, 1, false, 1, 3 | 4 | 128>());
+                        p.variants.push_back(march_variant_planned<P, VZ, 32, 16, 2, 1, false, 1, 3 | 128>());
+                        p.variants.push_back(march_variant_planned<P, VZ, 32, 16, 2, 1, false, 1, 3 | 4 | 128>());
                     }
                 }
             }
