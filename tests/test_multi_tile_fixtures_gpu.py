@@ -189,12 +189,13 @@ def _rank_worker(rank, world, port, name, nr, q):
 
 
 @pytest.mark.parametrize("world,nr", [(2, (2, 1, 1)), (8, (2, 2, 2))], ids=["2ranks", "8ranks"])
-@pytest.mark.parametrize("stencil", ["cube", "fsg_abc", "awp", "ssg2", "iso3dfd_sponge"])
+@pytest.mark.parametrize("stencil", ["cube", "fsg_abc", "awp", "ssg2", "iso3dfd_sponge", "tti"])
 def test_decomposed_runs_match_the_reference_fixture(gpu, stencil, world, nr):
     """N ranks on one device (IPC transport): the assembled lattice equals the REFERENCE's one-rank result at that size -- the checker
     is the fixture, not this library's own one-rank run (which tests/test_part_boxes_gpu.py and test_clusters_gpu.py compare bit for bit).
     awp / ssg2 / iso3dfd_sponge (end of round 6): one-part stages on generic marching shapes, which now have descriptor-reading twins --
-    over 2 x 2 x 2 ranks they run the planned / halves schedules instead of exterior slabs + interior."""
+    over 2 x 2 x 2 ranks they run the planned / halves schedules instead of exterior slabs + interior; likewise cube and tti on the
+    plane-ring kernel's twin (planned launches: their vars are read at mixed offsets, which rules the halves out)."""
     import multiprocessing as mp
     name = [n for n in CASES if INDEX[n]["stencil"] == stencil][0]
     meta = INDEX[name]

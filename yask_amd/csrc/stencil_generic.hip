@@ -50,29 +50,29 @@ void add_box_family(PartImpl& p, const char* suffix, bool set_default) {
     if constexpr (box_eligible<Q>() && box_wanted<Q>()) {
         constexpr int TZL = 32;          // (z tile = 32 lanes of 16 bytes)
         if constexpr (2 * BoxCfg<Q, VZ, TZL, 16, 1>::ring_reads() >= Q::n_reads) {
-            p.variants.push_back(box_variant<Q, VZ, TZL, 16, 1, 2, 1>());
+            p.variants.push_back(box_variant_planned<Q, VZ, TZL, 16, 1, 2, 1>());
             if (set_default) p.default_variant = (int)p.variants.size() - 1;
-            p.variants.push_back(box_variant<Q, VZ, TZL, 16, 1, 2, 1 | 4>());
-            p.variants.push_back(box_variant<Q, VZ, TZL, 8, 2, 2, 1>());
-            p.variants.push_back(box_variant<Q, VZ, TZL, 8, 2, 2, 1 | 4>());
+            p.variants.push_back(box_variant_planned<Q, VZ, TZL, 16, 1, 2, 1 | 4>());
+            p.variants.push_back(box_variant_planned<Q, VZ, TZL, 8, 2, 2, 1>());
+            p.variants.push_back(box_variant_planned<Q, VZ, TZL, 8, 2, 2, 1 | 4>());
         }
         if constexpr (2 * BoxCfg<Q, VZ, TZL, 8, 1, 80>::ring_reads() >= Q::n_reads && Q::n_reads > 130)
-            p.variants.push_back(box_variant<Q, VZ, TZL, 8, 1, 1, 1 | 4, 80>());
+            p.variants.push_back(box_variant_planned<Q, VZ, TZL, 8, 1, 1, 1 | 4, 80>());
         // where the 128 x 16 tile leaves groups without a ring, the half-height tile holds more of them in the same LDS
         if constexpr (BoxCfg<Q, VZ, TZL, 8, 1>::ring_reads() > BoxCfg<Q, VZ, TZL, 16, 1>::ring_reads() &&
                       2 * BoxCfg<Q, VZ, TZL, 8, 1>::ring_reads() >= Q::n_reads) {
-            p.variants.push_back(box_variant<Q, VZ, TZL, 8, 1, 2, 1 | 4>());
-            if constexpr (Q::n_reads > 130) p.variants.push_back(box_variant<Q, VZ, TZL, 8, 1, 1, 1 | 4>());
+            p.variants.push_back(box_variant_planned<Q, VZ, TZL, 8, 1, 2, 1 | 4>());
+            if constexpr (Q::n_reads > 130) p.variants.push_back(box_variant_planned<Q, VZ, TZL, 8, 1, 1, 1 | 4>());
             // ... and with 8-byte lanes (two points per thread) such a part fits 256 VGPRs without spilling: 512 threads, two waves
             // per SIMD where the 16-byte-lane shape above runs one (tti: 251 VGPRs, no scratch; 256 + 68 B without packed fp32)
-            if constexpr (Q::n_reads > 130 && VZ == 4) p.variants.push_back(box_variant<Q, 2, 64, 8, 1, 2, 1 | 4>());
+            if constexpr (Q::n_reads > 130 && VZ == 4) p.variants.push_back(box_variant_planned<Q, 2, 64, 8, 1, 2, 1 | 4>());
         }
         // parts that read small tables over a subset of the domain dims at offsets (kind 4; test_partial_3d: 59 of 79 reads): every such
         // read is live in registers from its load to its use -- with 16-byte lanes 950+ bytes of scratch per thread; 8-byte lanes halve it
         if constexpr (box_has_tables<Q>() && VZ == 4) {
-            p.variants.push_back(box_variant<Q, 2, 64, 8, 1, 2, 1 | 4>());
+            p.variants.push_back(box_variant_planned<Q, 2, 64, 8, 1, 2, 1 | 4>());
             // ... or one wave per SIMD with the whole register file (16-byte lanes, 128 x 8 tile: no scratch)
-            p.variants.push_back(box_variant<Q, VZ, 32, 8, 1, 1, 1 | 4>());
+            p.variants.push_back(box_variant_planned<Q, VZ, 32, 8, 1, 1, 1 | 4>());
         }
         // (the no-packed unit also twins the vector point kernel: tti's ran 8.29 -> 5.39 ms without packed adds)
         if (suffix[0]) p.variants.push_back(vecpt_variant<Q, VZ, 64, 4, 1>());

@@ -296,7 +296,9 @@ struct BoxAcc {
 // FL & 1: non-temporal output stores and centre-only operand loads (one-touch streams);
 // FL & 4: planes are requested TWO iterations before they are stored into the ring (two register sets; a workgroup's plane takes
 // 1-2.5 us, about a loaded HBM round trip)
-template <class P, int VZ, int TZL, int TYL, int RY, int MINW, int FL = 0, int LDS_KB = 160>
+// DESC: the twin that takes its tile and x range from a block descriptor (planned launches of a decomposed rank, ykh_plan.cpp) and signals
+// when done -- as in march_kernel; a block is self-contained (its prologue fills its own rings), so the planner may cut the box freely.
+template <class P, int VZ, int TZL, int TYL, int RY, int MINW, int FL = 0, int LDS_KB = 160, bool DESC = false>
 __global__ void __launch_bounds__(TZL* TYL, MINW) box_kernel(const PartArgs a) {
     typedef BoxCfg<P, VZ, TZL, TYL, RY, LDS_KB> C;
     typedef typename C::T T;
@@ -310,7 +312,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) box_kernel(const PartArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ykh_smem[];
     T* ring = reinterpret_cast<T*>(ykh_smem);
 
-    const BlockBox bb = block_box<VZ, C::TZ, C::TY, false>(a);
+    const BlockBox bb = block_box<VZ, C::TZ, C::TY, DESC>(a);
     const int tid = threadIdx.x;
     const int lz = tid % TZL, ly = tid / TZL;
     const int zt0 = bb.zt0, yt0 = bb.yt0, xs = bb.xs, xe = bb.xe;
@@ -492,6 +494,7 @@ __global__ void __launch_bounds__(TZL* TYL, MINW) box_kernel(const PartArgs a) {
     // (a trip of PD planes may run one plane past xe-1: loads are clamped, its stores fall under the x < xe test below)
     for (int x = xs; x < xe; x += PD)
         static_for<PD>([&](auto sc) { if (x + decltype(sc)::value < xe) plane(x + decltype(sc)::value, sc); });
+    if constexpr (DESC) block_done(a, bb.flags);
 }
 
 }  // namespace ykh

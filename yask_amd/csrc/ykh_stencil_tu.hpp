@@ -130,16 +130,16 @@ KernelVariant march_variant_planned() {
     return kv;
 }
 
-template <class P, int VZ, int TZL, int TYL, int RY, int MINW, int FL = 0, int LDS_KB = 160>
+template <class P, int VZ, int TZL, int TYL, int RY, int MINW, int FL = 0, int LDS_KB = 160, bool DESC = false>
 void launch_box(const PartArgs& a, dim3 grid, hipStream_t s) {
     typedef BoxCfg<P, VZ, TZL, TYL, RY, LDS_KB> C;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&box_kernel<P, VZ, TZL, TYL, RY, MINW, FL, LDS_KB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&box_kernel<P, VZ, TZL, TYL, RY, MINW, FL, LDS_KB, DESC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((box_kernel<P, VZ, TZL, TYL, RY, MINW, FL, LDS_KB>), grid, dim3(C::NT), C::lds_bytes, s, a);
+    hipLaunchKernelGGL((box_kernel<P, VZ, TZL, TYL, RY, MINW, FL, LDS_KB, DESC>), grid, dim3(C::NT), C::lds_bytes, s, a);
 }
 // Plane-ring marching kernel (ykh_box.hpp). Name: box_v<VZ>_z<tile z>_y<tile y>_r<rows per thread>[_nt][_p2][_l<LDS budget, KiB>]_w<min waves/SIMD>
 template <class P, int VZ, int TZL, int TYL, int RY, int MINW, int FL = 0, int LDS_KB = 160>
@@ -153,6 +153,14 @@ KernelVariant box_variant() {
     kv.vz = VZ;
     kv.func = reinterpret_cast<const void*>(&box_kernel<P, VZ, TZL, TYL, RY, MINW, FL, LDS_KB>);
     kv.xover = C::XOVER;
+    return kv;
+}
+// ... plus its descriptor-reading twin (planned launches of a decomposed rank; see march_variant_planned)
+template <class P, int VZ, int TZL, int TYL, int RY, int MINW, int FL = 0, int LDS_KB = 160>
+KernelVariant box_variant_planned() {
+    KernelVariant kv = box_variant<P, VZ, TZL, TYL, RY, MINW, FL, LDS_KB>();
+    kv.launch_desc = &launch_box<P, VZ, TZL, TYL, RY, MINW, FL, LDS_KB, true>;
+    kv.func_desc = reinterpret_cast<const void*>(&box_kernel<P, VZ, TZL, TYL, RY, MINW, FL, LDS_KB, true>);
     return kv;
 }
 
