@@ -4,6 +4,9 @@
 // (ykh_box.hpp: parts with many mixed-offset reads), the generic
 // marching kernel (all offset-read and written groups are full-dim vars, slabs fit the LDS, <= 48 groups) and
 // the linear-star kernel (the compiler found the linear star form).  Default = the most specialised one.
+// Every marching and plane-ring shape is registered WITH its descriptor-reading twin (march_variant_planned / box_variant_planned): a
+// decomposed rank runs a one-part stage on such a shape as a planned launch or as pipelined half-exchanges instead of exterior slabs +
+// interior (profiles/r6_generic_twins: awp blocks 1.23 -> 1.04 x the undivided sweep at 256^3); a twin that spills is never used.
 // Compiled once per stencil with -DYKH_GEN_HEADER="gen/<name>_cdna4_hip.hpp" -DYKH_GEN_NS=ykh_gen_<name>
 // (Makefile: GENERIC_STENCILS).  The hand-tuned registries (stencil_iso3dfd.hip, stencil_3axis.hip,
 // stencil_ssg.hip) list more tile shapes for the hot-path stencils.
